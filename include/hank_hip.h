@@ -1,0 +1,141 @@
+/*
+ * hank_hip.h — C ABI of the MI355X-native household block (the sequence-space JVP hot path).
+ *
+ * The reference (vasudeva-ram/Julia-NewtonRaphsonHANK) has no FFI; its boundary for this path is a
+ * set of Julia call signatures. Each entry point below names the reference interface it replaces;
+ * the Julia `ccall` shims that keep those signatures are in INTEGRATION.md / julia/HankHIP.jl.
+ *
+ * Conventions (all of them the reference's own):
+ *   - every array is fp64, column-major; policy / value / distribution matrices are n_a x n_e
+ *     with wealth fastest (ForwardIteration.jl:6-10); G = n_a*n_e; P = T-1 transition periods.
+ *   - Pi is the row-stochastic productivity transition, column-major: Pi[e + n_e*e2] = P(e -> e2)
+ *     (GeneralStructures.jl:500-525; used as V'*Pi' backward, KrusellSmith.jl:59, and D*Pi forward,
+ *     ForwardIteration.jl:280-284).
+ *   - "xhh" are the per-period household inputs the value function reads from xVals; for the
+ *     Krusell-Smith plugin that is (r_t, w_t) (KrusellSmith.jl:53-54): xhh[k + n_hh*t], n_hh = 2.
+ *   - tangent batches are Julia-natural: dxhh is (n_hh, P, N) column-major, dagg is (P, N).
+ *   - the caller owns every host buffer; the library copies in/out and retains no pointer past a
+ *     call; the context owns all device memory. A context is bound to the HIP device that was
+ *     current at hank_create, is not thread-safe, and host-pointer calls are synchronous on return.
+ *   - every function returns a status (0 = ok). Julia exceptions on this path become codes:
+ *     hank_last_error() carries the message the shim turns back into error(...).
+ *
+ * There is NO CPU fallback: every entry point fails with HANK_ERR_NO_DEVICE when no gfx950 device
+ * is usable.
+ */
+#ifndef HANK_HIP_H
+#define HANK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hank_ctx hank_ctx;
+
+enum {
+    HANK_OK = 0,
+    HANK_ERR_NO_DEVICE = 1,   /* no usable HIP device / HIP runtime error                          */
+    HANK_ERR_BAD_ARG = 2,     /* shape / argument errors (error(...) in the Julia callers)         */
+    HANK_ERR_KNOTS = 3,       /* Interpolations.jl: knot-vectors must be unique and sorted
+                                 (KrusellSmith.jl:69-72; acknowledged at SteadyState.jl:129-131)   */
+    HANK_ERR_DOMAIN = 4,      /* Julia DomainError: negative base under a non-integer power
+                                 (KrusellSmith.jl:59, :80)                                         */
+    HANK_ERR_NOT_READY = 5,   /* boundary / primal not set before a dependent call                 */
+    HANK_ERR_NONMONOTONE = 6, /* savings policy not monotone in wealth (cannot happen when the
+                                 knots check passes; guards the segmented Young push-forward)      */
+    HANK_ERR_NOMEM = 7
+};
+
+/* value-function families resolved from the YAML `function:` name (KrusellSmith.yaml:86,
+ * ModelParser.jl:338-342 / _lookup_fn :404-413). */
+enum { HANK_VF_KRUSELL_SMITH = 0 };
+
+/* The model-side constants BackwardIteration/ForwardIteration read from `model::SequenceModel`
+ * (GeneralStructures.jl:216-226): heterogeneity grids + params + compspec.T. */
+typedef struct {
+    int32_t n_a;         /* model.heterogeneity.wealth.n                                          */
+    int32_t n_e;         /* model.heterogeneity.productivity.n                                    */
+    int32_t T;           /* model.compspec.T ; P = T-1 periods are solved                         */
+    int32_t value_fn_id; /* HANK_VF_*                                                             */
+    const double *a_grid; /* [n_a] wealth grid, strictly increasing                                */
+    const double *z_grid; /* [n_e] productivity grid                                               */
+    const double *Pi;     /* [n_e*n_e] column-major row-stochastic                                 */
+    double beta, gamma, borrow_cons; /* model.params.β, γ, borrow_cons (KrusellSmith.jl:52)        */
+} hank_model;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int hank_create(const hank_model *model, hank_ctx **out);
+int hank_destroy(hank_ctx *ctx);
+const char *hank_last_error(const hank_ctx *ctx); /* never NULL; "" when the last call succeeded  */
+int hank_n_hh(const hank_ctx *ctx);               /* household inputs per period (KS: 2)          */
+
+/* Use the caller's HIP stream (a hipStream_t) for everything this context enqueues; NULL restores
+ * the context's own stream. */
+int hank_set_stream(hank_ctx *ctx, void *hip_stream);
+int hank_sync(hank_ctx *ctx);
+
+/* ---- boundary conditions ---------------------------------------------------------------------
+ * ss_end_value: terminal marginal value, `ss_end.value` (BackwardIteration.jl:85).
+ * ss_init_D:    initial distribution,   `ss_initial.D`  (ForwardIteration.jl:293).             */
+int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *ss_init_D);
+
+/* ---- the fused household block -----------------------------------------------------------------
+ * hank_primal  ==  ForwardIteration(BackwardIteration(x, ...), ...) on Float64
+ *                  (NewtonRaphson.jl:78-79 inside fullFunction, called at :91).
+ *   xhh[n_hh*P] -> agg_out[P] (the aggregate of the single heterogeneous variable, KD for KS:
+ *   dot(vec(policy_t), D_t) with the POST-transition D_t, ForwardIteration.jl:301-307).
+ *   Also records the linearisation every later hank_jvp uses.
+ * hank_jvp     ==  the partials of the same composition under Dual{Tag,Float64,N}, i.e. what
+ *                  JVP(fullFunction, x, y) (GeneralStructures.jl:542-550; NewtonRaphson.jl:95)
+ *                  pushes through the household block, for N tangent directions at once.
+ *   dxhh (n_hh, P, N) -> dagg_out (P, N).                                                        */
+int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out);
+int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out);
+
+/* Same, with DEVICE pointers (inputs already resident in HBM); enqueued on the context's stream,
+ * asynchronous: call hank_sync (or synchronise the stream) before reading the outputs.
+ * hank_primal_dev reports device-side errors (knots/domain) at the next hank_check. */
+int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out);
+int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_out);
+int hank_check(hank_ctx *ctx); /* sync + fetch the device error word of the last primal          */
+
+/* BackwardIteration's return value (BackwardIteration.jl:115): the policy sequence of the last
+ * hank_primal, P matrices of n_a x n_e -> out[P*G]; and its partials for the last hank_jvp,
+ * out[(G, P, N)] column-major (seqs_data[j][t] as Matrix{Dual}). */
+int hank_get_policy_seq(hank_ctx *ctx, double *out);
+int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out);
+/* The distribution path D_1..D_P of the last hank_primal -> out[P*G] (ForwardIteration.jl:297-300). */
+int hank_get_dist_seq(hank_ctx *ctx, double *out);
+
+/* ---- granular steps (step-level parity with the reference's functions) -------------------------
+ * hank_backward_step[_dual]  ==  model.value_fn(value_next, xVals, model) for the KS plugin
+ *   `ValueFunction` (KrusellSmith.jl:43-83): -> (Value, KD). The _dual form carries N partials:
+ *   dvalue_next/dvalue_out/dpolicy_out are (G, N) column-major, dxhh_t is (n_hh, N).
+ * hank_forward_step[_dual]   ==  transition_step(policy, D_prev, Λ_exog, dim, n_exog)
+ *   (ForwardIteration.jl:95-99, Young lottery :37-78) followed by dot(vec(policy), D_new)
+ *   (:305-307). Any policy is accepted here (no monotonicity requirement).                       */
+int hank_backward_step(hank_ctx *ctx, const double *value_next, const double *xhh_t,
+                       double *value_out, double *policy_out);
+int hank_backward_step_dual(hank_ctx *ctx, const double *value_next, const double *dvalue_next,
+                            const double *xhh_t, const double *dxhh_t, int32_t N,
+                            double *value_out, double *dvalue_out, double *policy_out,
+                            double *dpolicy_out);
+int hank_forward_step(hank_ctx *ctx, const double *policy, const double *D_prev, double *D_out,
+                      double *agg_out);
+int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dpolicy,
+                           const double *D_prev, const double *dD_prev, int32_t N, double *D_out,
+                           double *dD_out, double *agg_out, double *dagg_out);
+
+/* ---- measurement hooks (bench.py) ---------------------------------------------------------------
+ * Device time, in milliseconds, of the sweeps of the most recent hank_primal[_dev]/hank_jvp[_dev],
+ * from HIP events recorded on the context's stream around each sweep:
+ *   out[0] primal backward, out[1] primal forward, out[2] tangent backward, out[3] tangent forward.
+ * launches[k] = kernel launches inside sweep k. Valid after hank_sync. */
+int hank_last_timings(hank_ctx *ctx, double out_ms[4], int32_t launches[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HANK_HIP_H */

@@ -1,0 +1,107 @@
+"""Newton–Raphson for the perfect-foresight path — Python mirror of NewtonRaphson.jl (Boehl 2021).
+
+Same call surface (`NewtonRaphsonHANK(x_0, J̅, exog_paths, mod, ss_initial, ss_ending; ε)`,
+`y_Iteration(...)`); the hot path inside `fullFunction` — BackwardIteration → ForwardIteration —
+runs on the GPU. One difference in *cost*, not in results: the reference re-runs the whole primal
+pipeline inside every JVP (NewtonRaphson.jl:95, GeneralStructures.jl:546-547); here the primal
+sweep at x is recorded once by the Float64 call `fullFunction(x)` (:91) and every JVP of the inner
+loop reuses that linearisation (hank_jvp).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse.linalg as spla
+
+from .Aggregation import Residuals
+from .BackwardIteration import BackwardIteration, household_block, household_inputs
+from .dual import Dual
+from .ForwardIteration import ForwardIteration
+from .GeneralStructures import JVP, SequenceModel, assemble_full_xMat, vars_of_type
+
+
+def make_fullFunction(exog_paths, mod: SequenceModel, ss_initial, ss_ending):
+    """the closure of y_Iteration (NewtonRaphson.jl:77-83)."""
+
+    def fullFunction(x_Vec):
+        policy_seqs = BackwardIteration(x_Vec, exog_paths, mod, ss_ending, ss_initial=ss_initial)
+        agg_seqs = ForwardIteration(policy_seqs, mod, ss_initial)
+        padded_xMat = assemble_full_xMat(x_Vec, agg_seqs, exog_paths, mod, ss_initial, ss_ending)
+        return Residuals(padded_xMat, mod)
+
+    return fullFunction
+
+
+class LinearizedFunction:
+    """F(x) evaluated once + cheap J(x)·y products at that fixed x (the y-iteration's access pattern,
+    NewtonRaphson.jl:91-105). Tangent batches (n, N) go through ONE hank_jvp."""
+
+    def __init__(self, x, exog_paths, mod: SequenceModel, ss_initial, ss_ending):
+        self.x = np.asarray(x, dtype=np.float64)
+        self.mod, self.exog_paths, self.ss_initial, self.ss_ending = mod, exog_paths, ss_initial, ss_ending
+        self.hb = household_block(mod)
+        xhh, _ = household_inputs(self.x, exog_paths, mod)
+        self.hb.set_boundary(ss_ending.value, ss_initial.D)
+        self.agg = self.hb.primal(xhh)
+        het = vars_of_type(mod, "heterogeneous")
+        self.het = het
+        self.Fx = Residuals(assemble_full_xMat(self.x, {k: self.agg for k in het}, exog_paths, mod,
+                                               ss_initial, ss_ending), mod)
+
+    def jvp(self, y):
+        y = np.asarray(y, dtype=np.float64)
+        single = y.ndim == 1
+        xd = Dual.seed(self.x, y[:, None] if single else y)
+        _, dxhh = household_inputs(xd, self.exog_paths, self.mod)
+        dagg = self.hb.jvp(dxhh)
+        agg = {k: Dual(self.agg, dagg) for k in self.het}
+        res = Residuals(assemble_full_xMat(xd, agg, self.exog_paths, self.mod, self.ss_initial, self.ss_ending), self.mod)
+        return res.p[:, 0].copy() if single else res.p.copy()
+
+
+def _gmres(J, b, x0):
+    """IterativeSolvers.gmres!(x, A, b) defaults: restart = min(20, n), reltol = sqrt(eps),
+    warm start from x (NewtonRaphson.jl:97-98)."""
+    n = len(b)
+    x, _ = spla.gmres(J, b, x0=x0, rtol=np.sqrt(np.finfo(float).eps), atol=0.0, restart=min(20, n), maxiter=n)
+    return x
+
+
+def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, precond=None,
+                α: float = 1.0, γ: float = 1.5, ε: float = 1e-9, verbose: bool = False, max_inner: int = 10_000):
+    """inner fixed-point iteration for the search direction (NewtonRaphson.jl:65-114):
+    y ← y + α·J̅⁻¹(F(x) − J(x)·y), α = 0.5 hard-coded as in the reference (:102)."""
+    lin = LinearizedFunction(x, exog_paths, mod, ss_initial, ss_ending)
+    y = np.asarray(y0, dtype=np.float64)
+    n = len(y)
+    y_old, M, R = np.ones(n), np.ones(n), np.ones(n)
+    Fx = lin.Fx
+    i = 1
+    while ε < np.linalg.norm(y - y_old) and i < max_inner:
+        Λxy = lin.jvp(y)
+        R = _gmres(J̅, Fx - Λxy, R)
+        M = _gmres(J̅, Λxy, M)
+        ray = float(y @ M) / float(y @ y)
+        α = 0.5
+        y_old = y
+        y = y_old + α * R
+        i += 1
+        if verbose and i % 10 == 0:
+            print(f"y_Iteration {i}: α={α}  ‖y−y_old‖={np.linalg.norm(y - y_old)}  ray={ray}")
+    y_Iteration.last_jvp_count = i - 1
+    return y
+
+
+def NewtonRaphsonHANK(x_0, J̅, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, ε: float = 1e-9,
+                      verbose: bool = False):
+    """outer Newton loop (NewtonRaphson.jl:27-46): x ← x − y until ‖y‖ ≤ ε or 100 iterations."""
+    x = np.asarray(x_0, dtype=np.float64)
+    y = x.copy()
+    i = 1
+    while ε < np.linalg.norm(y) and i < 100:
+        y = y_Iteration(J̅, x, y, exog_paths, mod, ss_initial, ss_ending, verbose=verbose)
+        x = x - y
+        i += 1
+        if verbose:
+            print(f"Iteration: {i}, norm(y): {np.linalg.norm(y)}")
+    NewtonRaphsonHANK.iterations = i - 1
+    return x

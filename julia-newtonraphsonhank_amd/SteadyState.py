@@ -1,0 +1,150 @@
+"""Steady-state solver — host-side Python mirror of SteadyState.jl (north star: stays on the host).
+
+It manufactures the boundary inputs of the GPU hot path: `ss.value` (terminal marginal value),
+`ss.D` (initial distribution) and `ss.vars`. Algorithm as in the reference: Newton on the free
+endogenous prices (find_ss, SteadyState.jl:184-233) around an inner VFI on the value function
+(get_xVals, :111-154) and the stationary distribution by sparse linear solve
+(invariant_dist, ForwardIteration.jl:436-442). The price Jacobian is taken by forward differences
+instead of ForwardDiff.jacobian — only the fixed point matters.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from .Aggregation import Residuals
+from .ForwardIteration import make_endogenous_transition
+from .GeneralStructures import SequenceModel, invariant_dist, var_names, vars_of_type
+
+
+@dataclass
+class SteadyState:
+    """SteadyState.jl:21-27."""
+    vars: Dict[str, float]
+    policies: Dict[str, np.ndarray]
+    Λ: sp.csc_matrix
+    D: np.ndarray
+    value: np.ndarray
+
+
+class SSAssembler:
+    """variable roles + padded-matrix assembly for the steady-state Newton solve (SteadyState.jl:55-93)."""
+
+    def __init__(self, model: SequenceModel, ss_spec, vfi_tol: float | None = None):
+        self.model, self.ss_spec = model, ss_spec
+        self.all_keys = var_names(model)
+        self.free_keys = tuple(k for k in vars_of_type(model, "endogenous") if k not in ss_spec.fixed)
+        self.n_free = len(self.free_keys)
+        endog = [d for d in model.heterogeneity.values() if d.dim_type == "endogenous"]
+        exog = [d for d in model.heterogeneity.values() if d.dim_type == "exogenous"]
+        if len(endog) != 1:
+            raise ValueError("SSAssembler: exactly one endogenous heterogeneity dimension is currently supported")
+        self.endog_dim = endog[0]
+        self.n_exog = int(np.prod([d.n for d in exog])) if exog else 1
+        Λ_exog = sp.identity(self.endog_dim.n, format="csc")
+        for d in exog:
+            Λ_exog = sp.kron(sp.csc_matrix(d.transition.T), Λ_exog, format="csc")
+        self.Λ_exog = Λ_exog
+        # the reference stops the VFI at compspec.ε; a tighter default makes ss.value a clean fixed point
+        self.vfi_tol = vfi_tol if vfi_tol is not None else min(model.compspec.ε, 1e-11)
+        self._value_warm = None
+
+    def get_xVals(self, p_vec) -> Tuple[np.ndarray, np.ndarray, dict]:
+        """full length-n_v aggregate vector for price iterate p_vec + converged marginal value
+        (SteadyState.jl:111-154). VFI starts from ones (:132) or from the last converged value."""
+        model = self.model
+        xv = {k: 0.0 for k in self.all_keys}
+        for i, k in enumerate(self.free_keys):
+            xv[k] = float(p_vec[i])
+        for k, v in self.ss_spec.fixed.items():
+            xv[k] = float(v)
+        vf = model.value_fn
+        value = self._value_warm if self._value_warm is not None else np.ones((self.endog_dim.n, self.n_exog))
+        res = vf.host_steady_state_step(value, xv, model)
+        for _ in range(10_000):
+            value_new = res["Value"]
+            tol = np.max(np.abs(value_new - value))
+            value = value_new
+            if tol < self.vfi_tol:
+                break
+            res = vf.host_steady_state_step(value, xv, model)
+        Λ_endog = make_endogenous_transition(res[self.endog_dim.policy_var], self.endog_dim, self.n_exog)
+        D = invariant_dist((self.Λ_exog @ Λ_endog).T)
+        for k in vars_of_type(model, "heterogeneous"):
+            xv[k] = float(res[k].reshape(-1, order="F") @ D)
+        return np.array([xv[k] for k in self.all_keys]), res["Value"], res
+
+    def __call__(self, p_vec) -> np.ndarray:
+        cs = self.model.compspec
+        T_pad = 1 + cs.max_lag + cs.max_lead
+        xVals, value, _ = self.get_xVals(p_vec)
+        self._last_value = value
+        return np.tile(xVals[:, None], (1, T_pad))
+
+
+def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vfi_tol=None) -> SteadyState:
+    """Newton–Raphson on the free endogenous variables with step halving (SteadyState.jl:184-233)."""
+    asm = SSAssembler(model, ss_spec, vfi_tol)
+
+    def F(p):
+        return Residuals(asm(p), model)
+
+    def safe_eval(q):
+        try:
+            z = F(q)
+            return z if np.all(np.isfinite(z)) else np.full(len(z), np.inf)
+        except (ValueError, FloatingPointError):
+            return np.full(asm.n_free, np.inf)
+
+    p = np.array([ss_spec.guesses.get(k, 1.0) for k in asm.free_keys], dtype=np.float64)
+    ε = model.compspec.ε
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        z = F(p)
+        it, max_iter = 0, 100
+        while np.linalg.norm(z) > ε and it < max_iter:
+            if verbose:
+                print(f"  [{label}] Iteration {it}: residual norm = {np.linalg.norm(z)}")
+            asm._value_warm = getattr(asm, "_last_value", None)   # warm-start the inner VFI
+            J = np.empty((len(z), asm.n_free))
+            for j in range(asm.n_free):
+                h = 1e-6 * max(1.0, abs(p[j]))
+                q = p.copy()
+                q[j] += h
+                J[:, j] = (F(q) - z) / h
+            step = np.linalg.solve(J, z)
+            η, z_norm = 1.0, np.linalg.norm(z)
+            p_new = p - η * step
+            z_new = safe_eval(p_new)
+            while (not np.isfinite(np.linalg.norm(z_new))) or np.linalg.norm(z_new) > z_norm:
+                η /= 2
+                if not η > 1e-8:
+                    break
+                p_new = p - η * step
+                z_new = safe_eval(p_new)
+            p, z = p_new, z_new
+            it += 1
+    if it == max_iter:
+        import warnings
+        warnings.warn(f"find_ss [{label}]: did not converge in {max_iter} iterations (residual norm: {np.linalg.norm(z)})")
+    asm._value_warm = getattr(asm, "_last_value", None)
+    xVals, ss_value, _ = asm.get_xVals(p)
+    vars_ = {k: float(v) for k, v in zip(asm.all_keys, xVals)}
+    # one more value-function call at the converged value for clean policies (:222-225)
+    res = model.value_fn.host_steady_state_step(ss_value, vars_, model)
+    het_keys = vars_of_type(model, "heterogeneous")
+    policies = {k: res[k] for k in het_keys}
+    Λ_endog = make_endogenous_transition(policies[asm.endog_dim.policy_var], asm.endog_dim, asm.n_exog)
+    Λss = (asm.Λ_exog @ Λ_endog).tocsc()
+    D = invariant_dist(Λss.T)
+    return SteadyState(vars_, policies, Λss, D, ss_value)
+
+
+def get_SteadyStates(model: SequenceModel, verbose: bool = False, vfi_tol=None):
+    """both steady states (SteadyState.jl:245-259); one solve when the specs are the same object."""
+    ss_initial = find_ss(model, model.ss_initial, "initial", verbose, vfi_tol)
+    if model.ss_initial is model.ss_ending:
+        return ss_initial, ss_initial
+    return ss_initial, find_ss(model, model.ss_ending, "ending", verbose, vfi_tol)

@@ -1,0 +1,588 @@
+// hank_hip.hip — context, hipGraph-captured sweeps and the C ABI (include/hank_hip.h) of the
+// MI355X household block. Both sweeps are strict recurrences in t (value_t needs value_{t+1},
+// D_t needs D_{t-1}); every period is one kernel whose X half of period t-1 is fused behind the
+// Y half of period t, so the loop-carried state only crosses a launch boundary once per period,
+// and the 2(T-1) dependent launches are replayed from hipGraphs (no host launch cost).
+#include "hank_kernels.h"
+#include "../../include/hank_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace hank;
+
+struct TanWork {
+    int N = 0;
+    TanGeom g{};
+    double *dxhh = nullptr;   // (2,P,N) staging for the host-pointer entry
+    double *dxr = nullptr, *dxw = nullptr;
+    double *ds[2] = {nullptr, nullptr};
+    double *dD[2] = {nullptr, nullptr};
+    double *dpol = nullptr;
+    double *aggpart = nullptr;
+    double *dagg = nullptr;     // [P][N]
+    double *dagg_cm = nullptr;  // (P,N) column-major
+    int nbx = 0;
+    hipGraphExec_t g_back = nullptr, g_fwd = nullptr;
+    bool valid = false;  // dpol holds the partials of the current primal
+};
+
+struct hank_ctx {
+    int device = 0;
+    Consts c{};
+    Record R{};
+    int T = 0;
+    double *d_a = nullptr, *d_z = nullptr, *d_Pi = nullptr;
+    double *d_ss_value = nullptr, *d_ss_D = nullptr;  // d_ss_D aliases Dseq[0]
+    double *d_xhh = nullptr, *d_agg = nullptr, *d_aggpart = nullptr;
+    int *d_err = nullptr;
+    int nbp = 0;  // row blocks of the primal kernels
+    bool boundary_set = false, primal_done = false;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipGraphExec_t g_pback = nullptr, g_pfwd = nullptr;
+    hipEvent_t ev[8] = {};
+    bool ev_valid[4] = {false, false, false, false};
+    int launches[4] = {0, 0, 0, 0};
+    TanWork tw;
+    char errmsg[512] = {0};
+};
+
+static int fail(hank_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->errmsg, sizeof(ctx->errmsg), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HIPC(ctx, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? HANK_ERR_NOMEM : HANK_ERR_NO_DEVICE,   \
+                        "HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_),       \
+                        __FILE__, __LINE__, #call);                                             \
+    } while (0)
+
+template <typename T>
+static hipError_t dmalloc(T **p, size_t count) {
+    return hipMalloc((void **)p, count * sizeof(T) > 0 ? count * sizeof(T) : 8);
+}
+
+static size_t primal_lds(const Consts &c) { return sizeof(double) * ((size_t)c.n_e * RBP + (size_t)c.n_e * c.n_e + 16); }
+
+static void free_tanwork(TanWork &w) {
+    if (w.g_back) (void)hipGraphExecDestroy(w.g_back);
+    if (w.g_fwd) (void)hipGraphExecDestroy(w.g_fwd);
+    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw);
+    (void)hipFree(w.ds[0]); (void)hipFree(w.ds[1]); (void)hipFree(w.dD[0]); (void)hipFree(w.dD[1]);
+    (void)hipFree(w.dpol); (void)hipFree(w.aggpart); (void)hipFree(w.dagg); (void)hipFree(w.dagg_cm);
+    w = TanWork();
+}
+
+// ---- tangent kernel dispatch over the compile-time column count ---------------------------------
+#define NE_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+
+static void launch_tan_back(hank_ctx *ctx, TanWork &w, int t, const double *dsIn, double *dsOut, hipStream_t s) {
+    const int RB = TAN_THREADS >> w.g.lgNC;
+    dim3 grid((ctx->c.n_a + RB - 1) / RB, (w.N + w.g.NC - 1) / w.g.NC);
+    switch (ctx->c.n_e) {
+#define X(NE) case NE: hipLaunchKernelGGL(k_tan_back<NE>, grid, dim3(TAN_THREADS), 0, s, ctx->c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, t, dsIn, dsOut, w.dpol); break;
+        NE_CASES(X)
+#undef X
+    }
+}
+static void launch_tan_fwd(hank_ctx *ctx, TanWork &w, int t, const double *dDin, double *dDout, hipStream_t s) {
+    const int RB = TAN_THREADS >> w.g.lgNC;
+    dim3 grid((ctx->c.n_a + RB - 1) / RB, (w.N + w.g.NC - 1) / w.g.NC);
+    switch (ctx->c.n_e) {
+#define X(NE) case NE: hipLaunchKernelGGL(k_tan_fwd<NE>, grid, dim3(TAN_THREADS), 0, s, ctx->c, ctx->R, w.g, t, dDin, dDout, w.dpol, w.aggpart); break;
+        NE_CASES(X)
+#undef X
+    }
+}
+
+// ---- graph construction -----------------------------------------------------------------------
+static int end_capture(hank_ctx *ctx, hipGraphExec_t *out) {
+    hipGraph_t graph = nullptr;
+    HIPC(ctx, hipStreamEndCapture(ctx->own_stream, &graph));
+    HIPC(ctx, hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
+    HIPC(ctx, hipGraphDestroy(graph));
+    HIPC(ctx, hipGetLastError());
+    return HANK_OK;
+}
+
+static int build_primal_graphs(hank_ctx *ctx) {
+    const Consts &c = ctx->c;
+    const int P = c.P;
+    hipStream_t s = ctx->own_stream;
+    const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
+    const size_t lds = primal_lds(c);
+    // backward: X of the last period from the terminal value, then P fused Y;X steps, then lottery
+    HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    (void)hipMemsetAsync(ctx->d_err, 0, 4 * sizeof(int), s);
+    hipLaunchKernelGGL(k_egm_X, grd, blk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
+                       ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1);
+    for (int t = P - 1; t >= 0; t--)
+        hipLaunchKernelGGL(k_egm_step, grd, blk, lds, s, c, ctx->R, ctx->d_xhh, t, ctx->d_err);
+    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (size_t)c.n_a, s, c, ctx->R, P * c.n_e, ctx->d_err);
+    int rc = end_capture(ctx, &ctx->g_pback);
+    if (rc) return rc;
+    // forward
+    HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int t = 0; t < P; t++)
+        hipLaunchKernelGGL(k_dist_step, grd, blk, lds, s, c, ctx->R, t, ctx->d_aggpart);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((P + 255) / 256), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, P, ctx->d_agg);
+    rc = end_capture(ctx, &ctx->g_pfwd);
+    ctx->launches[0] = P + 2;
+    ctx->launches[1] = P + 1;
+    return rc;
+}
+
+static int ensure_tanwork(hank_ctx *ctx, int N) {
+    TanWork &w = ctx->tw;
+    if (w.N == N && w.g_back) return HANK_OK;
+    free_tanwork(w);
+    const Consts &c = ctx->c;
+    const size_t P = c.P, G = c.G;
+    w.N = N;
+    int NC = 1, lg = 0;
+    while (NC < N && NC < 64) { NC <<= 1; lg++; }
+    w.g.N = N; w.g.NC = NC; w.g.lgNC = lg;
+    const int RB = TAN_THREADS / NC;
+    w.nbx = (c.n_a + RB - 1) / RB;
+    HIPC(ctx, dmalloc(&w.dxhh, 2 * P * N));
+    HIPC(ctx, dmalloc(&w.dxr, P * N));
+    HIPC(ctx, dmalloc(&w.dxw, P * N));
+    for (int k = 0; k < 2; k++) {
+        HIPC(ctx, dmalloc(&w.ds[k], G * N));
+        HIPC(ctx, dmalloc(&w.dD[k], G * N));
+    }
+    HIPC(ctx, dmalloc(&w.dpol, P * G * N));
+    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)w.nbx * N));
+    HIPC(ctx, dmalloc(&w.dagg, P * N));
+    HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
+
+    hipStream_t s = ctx->own_stream;
+    const int RBt = RB;
+    const dim3 grid((c.n_a + RBt - 1) / RBt, (N + NC - 1) / NC);
+    const int PN = (int)(P * N);
+    // backward tangent sweep
+    HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
+    hipLaunchKernelGGL(k_tan_back_init, grid, dim3(TAN_THREADS), 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, (int)P - 1, w.ds[0]);
+    int cur = 0;
+    for (int t = (int)P - 1; t >= 0; t--) {
+        launch_tan_back(ctx, w, t, w.ds[cur], w.ds[cur ^ 1], s);
+        cur ^= 1;
+    }
+    int rc = end_capture(ctx, &w.g_back);
+    if (rc) return rc;
+    // forward tangent sweep
+    HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    (void)hipMemsetAsync(w.dD[0], 0, sizeof(double) * G * N, s);  // dD_0 = 0 (ForwardIteration.jl:293)
+    cur = 0;
+    for (int t = 0; t < (int)P; t++) {
+        launch_tan_fwd(ctx, w, t, w.dD[cur], w.dD[cur ^ 1], s);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_reduce_parts, dim3((PN + 255) / 256), dim3(256), 0, s, w.aggpart, w.nbx, N, PN, w.dagg);
+    hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
+    rc = end_capture(ctx, &w.g_fwd);
+    ctx->launches[2] = (int)P + 2;
+    ctx->launches[3] = (int)P + 2;
+    return rc;
+}
+
+static int fetch_device_error(hank_ctx *ctx) {
+    int e[4] = {0, 0, 0, 0};
+    HIPC(ctx, hipMemcpyAsync(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    if (e[0] == 0) return HANK_OK;
+    ctx->primal_done = false;
+    switch (e[0]) {
+    case ERR_KNOTS:
+        return fail(ctx, HANK_ERR_KNOTS,
+                    "knot-vectors must be unique and sorted in increasing order (EGM implied state, "
+                    "period %d, productivity state %d, wealth index %d)", e[1] + 1, e[2] + 1, e[3] + 1);
+    case ERR_DOMAIN:
+        return fail(ctx, HANK_ERR_DOMAIN,
+                    "DomainError: negative base under a non-integer power (period %d, productivity "
+                    "state %d, wealth index %d)", e[1] + 1, e[2] + 1, e[3] + 1);
+    case ERR_NONMONO:
+        return fail(ctx, HANK_ERR_NONMONOTONE,
+                    "savings policy is not monotone in wealth (period %d, productivity state %d, "
+                    "wealth index %d)", e[1] + 1, e[2] + 1, e[3] + 1);
+    default:
+        return fail(ctx, HANK_ERR_BAD_ARG, "unknown device error %d", e[0]);
+    }
+}
+
+// ================================ C ABI =========================================================
+extern "C" {
+
+const char *hank_last_error(const hank_ctx *ctx) { return ctx ? ctx->errmsg : "null context"; }
+int hank_n_hh(const hank_ctx *) { return 2; }
+
+int hank_create(const hank_model *m, hank_ctx **out) {
+    if (!m || !out) return HANK_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return HANK_ERR_NO_DEVICE;
+    hank_ctx *ctx = new (std::nothrow) hank_ctx();
+    if (!ctx) return HANK_ERR_NOMEM;
+    *out = ctx;  // returned even on failure so the caller can read hank_last_error, then destroy
+    if (m->n_a < 2 || m->n_e < 1 || m->n_e > 16 || m->T < 2)
+        return fail(ctx, HANK_ERR_BAD_ARG, "bad shape: n_a=%d (>=2), n_e=%d (1..16), T=%d (>=2)", m->n_a, m->n_e, m->T);
+    if (m->value_fn_id != HANK_VF_KRUSELL_SMITH)
+        return fail(ctx, HANK_ERR_BAD_ARG, "unknown value function id %d", m->value_fn_id);
+    if (!m->a_grid || !m->z_grid || !m->Pi) return fail(ctx, HANK_ERR_BAD_ARG, "null grid pointer");
+    for (int i = 1; i < m->n_a; i++)
+        if (!(m->a_grid[i] > m->a_grid[i - 1])) return fail(ctx, HANK_ERR_BAD_ARG, "wealth grid must be strictly increasing (index %d)", i + 1);
+    HIPC(ctx, hipGetDevice(&ctx->device));
+    hipDeviceProp_t prop;
+    HIPC(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ctx, HANK_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", ctx->device, prop.gcnArchName);
+    Consts &c = ctx->c;
+    c.n_a = m->n_a; c.n_e = m->n_e; c.G = m->n_a * m->n_e; c.P = m->T - 1;
+    c.beta = m->beta; c.gamma = m->gamma; c.bc = m->borrow_cons;
+    ctx->T = m->T;
+    const size_t P = c.P, G = c.G;
+    if ((size_t)c.n_a * sizeof(int) > 150 * 1024) return fail(ctx, HANK_ERR_BAD_ARG, "n_a=%d too large for the LDS-staged lottery", c.n_a);
+    HIPC(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    for (int k = 0; k < 8; k++) HIPC(ctx, hipEventCreate(&ctx->ev[k]));
+    HIPC(ctx, dmalloc(&ctx->d_a, c.n_a));
+    HIPC(ctx, dmalloc(&ctx->d_z, c.n_e));
+    HIPC(ctx, dmalloc(&ctx->d_Pi, (size_t)c.n_e * c.n_e));
+    HIPC(ctx, hipMemcpy(ctx->d_a, m->a_grid, sizeof(double) * c.n_a, hipMemcpyHostToDevice));
+    HIPC(ctx, hipMemcpy(ctx->d_z, m->z_grid, sizeof(double) * c.n_e, hipMemcpyHostToDevice));
+    HIPC(ctx, hipMemcpy(ctx->d_Pi, m->Pi, sizeof(double) * c.n_e * c.n_e, hipMemcpyHostToDevice));
+    c.a = ctx->d_a; c.z = ctx->d_z; c.Pi = ctx->d_Pi;
+    Record &R = ctx->R;
+    HIPC(ctx, dmalloc(&R.s, P * G)); HIPC(ctx, dmalloc(&R.kc, P * G));
+    HIPC(ctx, dmalloc(&R.A, P * G)); HIPC(ctx, dmalloc(&R.B, P * G));
+    HIPC(ctx, dmalloc(&R.u, P * G)); HIPC(ctx, dmalloc(&R.v, P * G));
+    HIPC(ctx, dmalloc(&R.pol, P * G)); HIPC(ctx, dmalloc(&R.lw, P * G));
+    HIPC(ctx, dmalloc(&R.ig, P * G)); HIPC(ctx, dmalloc(&R.Dseq, (P + 1) * G));
+    HIPC(ctx, dmalloc(&R.ib, P * G)); HIPC(ctx, dmalloc(&R.lo, P * G));
+    HIPC(ctx, dmalloc(&R.start, P * (size_t)c.n_e * (c.n_a + 1)));
+    HIPC(ctx, dmalloc(&ctx->d_ss_value, G));
+    ctx->d_ss_D = R.Dseq;
+    ctx->nbp = (c.n_a + RBP - 1) / RBP;
+    HIPC(ctx, dmalloc(&ctx->d_xhh, 2 * P));
+    HIPC(ctx, dmalloc(&ctx->d_agg, P));
+    HIPC(ctx, dmalloc(&ctx->d_aggpart, P * (size_t)ctx->nbp));
+    HIPC(ctx, dmalloc(&ctx->d_err, 4));
+    HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
+    int rc = build_primal_graphs(ctx);
+    if (rc) return rc;
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+int hank_destroy(hank_ctx *ctx) {
+    if (!ctx) return HANK_OK;
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+    free_tanwork(ctx->tw);
+    if (ctx->g_pback) (void)hipGraphExecDestroy(ctx->g_pback);
+    if (ctx->g_pfwd) (void)hipGraphExecDestroy(ctx->g_pfwd);
+    Record &R = ctx->R;
+    (void)hipFree(R.s); (void)hipFree(R.kc); (void)hipFree(R.A); (void)hipFree(R.B); (void)hipFree(R.u); (void)hipFree(R.v);
+    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start);
+    (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
+    (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
+    for (int k = 0; k < 8; k++)
+        if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return HANK_OK;
+}
+
+int hank_set_stream(hank_ctx *ctx, void *hip_stream) {
+    if (!ctx) return HANK_ERR_BAD_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return HANK_OK;
+}
+
+int hank_sync(hank_ctx *ctx) {
+    if (!ctx) return HANK_ERR_BAD_ARG;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return HANK_OK;
+}
+
+int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *ss_init_D) {
+    if (!ctx || !ss_end_value || !ss_init_D) return fail(ctx, HANK_ERR_BAD_ARG, "null boundary pointer");
+    const size_t G = ctx->c.G;
+    HIPC(ctx, hipMemcpyAsync(ctx->d_ss_value, ss_end_value, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->d_ss_D, ss_init_D, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->boundary_set = true;
+    ctx->primal_done = false;
+    ctx->tw.valid = false;
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+static int run_primal(hank_ctx *ctx) {
+    HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    HIPC(ctx, hipGraphLaunch(ctx->g_pback, ctx->stream));
+    HIPC(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPC(ctx, hipGraphLaunch(ctx->g_pfwd, ctx->stream));
+    HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    ctx->ev_valid[0] = ctx->ev_valid[1] = true;
+    ctx->primal_done = true;
+    ctx->tw.valid = false;
+    return HANK_OK;
+}
+
+int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
+    if (!ctx || !d_xhh) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
+    if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    const size_t P = ctx->c.P;
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * 2 * P, hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = run_primal(ctx);
+    if (rc) return rc;
+    if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+    return HANK_OK;
+}
+
+int hank_check(hank_ctx *ctx) {
+    if (!ctx) return HANK_ERR_BAD_ARG;
+    return fetch_device_error(ctx);
+}
+
+int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
+    if (!ctx || !xhh) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
+    if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    const size_t P = ctx->c.P;
+    for (size_t t = 0; t < P; t++)
+        if (!(1.0 + xhh[2 * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * 2 * P, hipMemcpyHostToDevice, ctx->stream));
+    int rc = run_primal(ctx);
+    if (rc) return rc;
+    rc = fetch_device_error(ctx);
+    if (rc) return rc;
+    if (agg_out) {
+        HIPC(ctx, hipMemcpyAsync(agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+static int run_jvp(hank_ctx *ctx) {
+    TanWork &w = ctx->tw;
+    HIPC(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIPC(ctx, hipGraphLaunch(w.g_back, ctx->stream));
+    HIPC(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    HIPC(ctx, hipGraphLaunch(w.g_fwd, ctx->stream));
+    HIPC(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    ctx->ev_valid[2] = ctx->ev_valid[3] = true;
+    w.valid = true;
+    return HANK_OK;
+}
+
+int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_out) {
+    if (!ctx || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
+    if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
+    int rc = ensure_tanwork(ctx, N);
+    if (rc) return rc;
+    const size_t P = ctx->c.P;
+    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, d_dxhh, sizeof(double) * 2 * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = run_jvp(ctx);
+    if (rc) return rc;
+    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    return HANK_OK;
+}
+
+int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
+    if (!ctx || !dxhh || !dagg_out || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
+    if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
+    int rc = ensure_tanwork(ctx, N);
+    if (rc) return rc;
+    const size_t P = ctx->c.P;
+    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * 2 * P * N, hipMemcpyHostToDevice, ctx->stream));
+    rc = run_jvp(ctx);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+int hank_last_timings(hank_ctx *ctx, double out_ms[4], int32_t launches[4]) {
+    if (!ctx || !out_ms) return HANK_ERR_BAD_ARG;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    const int a[4] = {0, 1, 3, 4};
+    for (int k = 0; k < 4; k++) {
+        out_ms[k] = -1.0;
+        if (ctx->ev_valid[k]) {
+            float ms = 0.f;
+            HIPC(ctx, hipEventElapsedTime(&ms, ctx->ev[a[k]], ctx->ev[a[k] + 1]));
+            out_ms[k] = ms;
+        }
+        if (launches) launches[k] = ctx->launches[k];
+    }
+    return HANK_OK;
+}
+
+int hank_get_policy_seq(hank_ctx *ctx, double *out) {
+    if (!ctx || !out) return HANK_ERR_BAD_ARG;
+    if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "no primal sweep has been run");
+    HIPC(ctx, hipMemcpyAsync(out, ctx->R.pol, sizeof(double) * (size_t)ctx->c.P * ctx->c.G, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return HANK_OK;
+}
+
+int hank_get_dist_seq(hank_ctx *ctx, double *out) {
+    if (!ctx || !out) return HANK_ERR_BAD_ARG;
+    if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "no primal sweep has been run");
+    HIPC(ctx, hipMemcpyAsync(out, ctx->R.Dseq + ctx->c.G, sizeof(double) * (size_t)ctx->c.P * ctx->c.G, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return HANK_OK;
+}
+
+int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
+    if (!ctx || !out) return HANK_ERR_BAD_ARG;
+    TanWork &w = ctx->tw;
+    if (!w.valid || w.N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
+    const size_t total = (size_t)ctx->c.P * ctx->c.G * N;
+    double *tmp = nullptr;
+    HIPC(ctx, dmalloc(&tmp, total));
+    hipLaunchKernelGGL(k_export_dpol, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w.dpol, ctx->c.G, ctx->c.P, N, tmp);
+    hipError_t e1 = hipMemcpyAsync(out, tmp, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    HIPC(ctx, e1);
+    HIPC(ctx, e2);
+    return HANK_OK;
+}
+
+}  // extern "C"
+
+// ---- granular steps ---------------------------------------------------------------------------
+struct Scratch {  // frees its device buffers on scope exit
+    std::vector<void *> p;
+    ~Scratch() { for (void *q : p) (void)hipFree(q); }
+    template <typename T> hipError_t alloc(T **out, size_t n) {
+        hipError_t e = dmalloc(out, n);
+        if (e == hipSuccess) p.push_back(*out);
+        return e;
+    }
+};
+
+static int granular_backward(hank_ctx *ctx, const double *value_next, const double *dvalue_next,
+                             const double *xhh_t, const double *dxhh_t, int N, double *value_out,
+                             double *dvalue_out, double *policy_out, double *dpolicy_out) {
+    if (!ctx || !value_next || !xhh_t || !value_out || !policy_out) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
+    if (N > 0 && (!dvalue_next || !dxhh_t || !dvalue_out || !dpolicy_out)) return fail(ctx, HANK_ERR_BAD_ARG, "null tangent pointer");
+    const Consts &c = ctx->c;
+    const size_t G = c.G;
+    hipStream_t s = ctx->stream;
+    Scratch sc;
+    double *Vin, *xt, *sK, *kc, *A, *B, *u, *v, *pol, *Vout;
+    int *ib;
+    HIPC(ctx, sc.alloc(&Vin, G)); HIPC(ctx, sc.alloc(&xt, 2)); HIPC(ctx, sc.alloc(&sK, G)); HIPC(ctx, sc.alloc(&kc, G));
+    HIPC(ctx, sc.alloc(&A, G)); HIPC(ctx, sc.alloc(&B, G)); HIPC(ctx, sc.alloc(&u, G)); HIPC(ctx, sc.alloc(&v, G));
+    HIPC(ctx, sc.alloc(&pol, G)); HIPC(ctx, sc.alloc(&Vout, G)); HIPC(ctx, sc.alloc(&ib, G));
+    if (!(1.0 + xhh_t[0] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive");
+    HIPC(ctx, hipMemcpyAsync(Vin, value_next, sizeof(double) * G, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemcpyAsync(xt, xhh_t, sizeof(double) * 2, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, 4 * sizeof(int), s));
+    const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
+    hipLaunchKernelGGL(k_egm_X, grd, blk, primal_lds(c), s, c, Vin, xt, sK, kc, ctx->d_err, 0);
+    hipLaunchKernelGGL(k_egm_Y, grd, blk, 0, s, c, sK, xhh_t[0], xhh_t[1], pol, ib, A, B, u, v, Vout, ctx->d_err, 0);
+    HIPC(ctx, hipGetLastError());
+    const bool was_done = ctx->primal_done;
+    int rc = fetch_device_error(ctx);
+    ctx->primal_done = was_done;
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(value_out, Vout, sizeof(double) * G, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipMemcpyAsync(policy_out, pol, sizeof(double) * G, hipMemcpyDeviceToHost, s));
+    if (N > 0) {
+        double *dVin, *dr, *dw, *ds, *dpol, *dV;
+        HIPC(ctx, sc.alloc(&dVin, G * N)); HIPC(ctx, sc.alloc(&dr, N)); HIPC(ctx, sc.alloc(&dw, N));
+        HIPC(ctx, sc.alloc(&ds, G * N)); HIPC(ctx, sc.alloc(&dpol, G * N)); HIPC(ctx, sc.alloc(&dV, G * N));
+        std::vector<double> hr(N), hw(N);
+        for (int n = 0; n < N; n++) { hr[n] = dxhh_t[2 * n]; hw[n] = dxhh_t[2 * n + 1]; }
+        HIPC(ctx, hipMemcpyAsync(dVin, dvalue_next, sizeof(double) * G * N, hipMemcpyHostToDevice, s));
+        HIPC(ctx, hipMemcpyAsync(dr, hr.data(), sizeof(double) * N, hipMemcpyHostToDevice, s));
+        HIPC(ctx, hipMemcpyAsync(dw, hw.data(), sizeof(double) * N, hipMemcpyHostToDevice, s));
+        const unsigned nb = (unsigned)((G * N + 255) / 256);
+        hipLaunchKernelGGL(k_tan_X, dim3(nb), dim3(256), 0, s, c, kc, sK, xhh_t[0], dr, dw, N, dVin, ds);
+        hipLaunchKernelGGL(k_tan_Y, dim3(nb), dim3(256), 0, s, c, ib, A, B, u, v, dr, dw, N, ds, dpol, dV);
+        HIPC(ctx, hipGetLastError());
+        HIPC(ctx, hipMemcpyAsync(dvalue_out, dV, sizeof(double) * G * N, hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipMemcpyAsync(dpolicy_out, dpol, sizeof(double) * G * N, hipMemcpyDeviceToHost, s));
+    }
+    HIPC(ctx, hipStreamSynchronize(s));
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+extern "C" {
+int hank_backward_step(hank_ctx *ctx, const double *value_next, const double *xhh_t, double *value_out, double *policy_out) {
+    return granular_backward(ctx, value_next, nullptr, xhh_t, nullptr, 0, value_out, nullptr, policy_out, nullptr);
+}
+int hank_backward_step_dual(hank_ctx *ctx, const double *value_next, const double *dvalue_next,
+                            const double *xhh_t, const double *dxhh_t, int32_t N, double *value_out,
+                            double *dvalue_out, double *policy_out, double *dpolicy_out) {
+    if (N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "N must be >= 1");
+    return granular_backward(ctx, value_next, dvalue_next, xhh_t, dxhh_t, N, value_out, dvalue_out, policy_out, dpolicy_out);
+}
+}  // extern "C"
+
+static int granular_forward(hank_ctx *ctx, const double *policy, const double *dpolicy, const double *D_prev,
+                            const double *dD_prev, int N, double *D_out, double *dD_out, double *agg_out, double *dagg_out) {
+    if (!ctx || !policy || !D_prev || !D_out) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
+    if (N > 0 && (!dpolicy || !dD_prev || !dD_out)) return fail(ctx, HANK_ERR_BAD_ARG, "null tangent pointer");
+    const Consts &c = ctx->c;
+    const size_t G = c.G, W = 1 + (size_t)N;
+    hipStream_t s = ctx->stream;
+    Scratch sc;
+    double *pol, *dpol = nullptr, *Dp, *dDp = nullptr, *Dmid, *Do, *dDo = nullptr, *aggterm, *aggv;
+    HIPC(ctx, sc.alloc(&pol, G)); HIPC(ctx, sc.alloc(&Dp, G)); HIPC(ctx, sc.alloc(&Dmid, G * W));
+    HIPC(ctx, sc.alloc(&Do, G)); HIPC(ctx, sc.alloc(&aggterm, G * W)); HIPC(ctx, sc.alloc(&aggv, W));
+    HIPC(ctx, sc.alloc(&dpol, G * (N ? N : 1))); HIPC(ctx, sc.alloc(&dDp, G * (N ? N : 1))); HIPC(ctx, sc.alloc(&dDo, G * (N ? N : 1)));
+    HIPC(ctx, hipMemcpyAsync(pol, policy, sizeof(double) * G, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemcpyAsync(Dp, D_prev, sizeof(double) * G, hipMemcpyHostToDevice, s));
+    if (N > 0) {
+        HIPC(ctx, hipMemcpyAsync(dpol, dpolicy, sizeof(double) * G * N, hipMemcpyHostToDevice, s));
+        HIPC(ctx, hipMemcpyAsync(dDp, dD_prev, sizeof(double) * G * N, hipMemcpyHostToDevice, s));
+    }
+    HIPC(ctx, hipMemsetAsync(Dmid, 0, sizeof(double) * G * W, s));
+    const unsigned nb = (unsigned)((G * W + 255) / 256);
+    hipLaunchKernelGGL(k_scatter_general, dim3(nb), dim3(256), 0, s, c, pol, dpol, Dp, dDp, N, Dmid);
+    hipLaunchKernelGGL(k_mix_general, dim3(nb), dim3(256), 0, s, c, Dmid, pol, dpol, N, Do, dDo, aggterm);
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)W), dim3(256), 0, s, aggterm, (int)G, (int)W, aggv);
+    HIPC(ctx, hipGetLastError());
+    std::vector<double> hagg(W);
+    HIPC(ctx, hipMemcpyAsync(D_out, Do, sizeof(double) * G, hipMemcpyDeviceToHost, s));
+    if (N > 0) HIPC(ctx, hipMemcpyAsync(dD_out, dDo, sizeof(double) * G * N, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipMemcpyAsync(hagg.data(), aggv, sizeof(double) * W, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipStreamSynchronize(s));
+    if (agg_out) *agg_out = hagg[0];
+    if (dagg_out) for (int n = 0; n < N; n++) dagg_out[n] = hagg[1 + n];
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+extern "C" {
+int hank_forward_step(hank_ctx *ctx, const double *policy, const double *D_prev, double *D_out, double *agg_out) {
+    return granular_forward(ctx, policy, nullptr, D_prev, nullptr, 0, D_out, nullptr, agg_out, nullptr);
+}
+int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dpolicy, const double *D_prev,
+                           const double *dD_prev, int32_t N, double *D_out, double *dD_out, double *agg_out, double *dagg_out) {
+    if (N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "N must be >= 1");
+    return granular_forward(ctx, policy, dpolicy, D_prev, dD_prev, N, D_out, dD_out, agg_out, dagg_out);
+}
+
+}  // extern "C"

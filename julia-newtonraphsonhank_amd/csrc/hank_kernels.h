@@ -1,0 +1,538 @@
+// hank_kernels.h — CDNA4 (gfx950) kernels of the household block. fp64 throughout, no MFMA:
+// the path is interpolation / 2-nnz SpMV / reductions (HBM-bound), the only contraction is the
+// n_e x n_e productivity mixing.
+//
+// Data layout in HBM (per context, P = T-1 periods, G = n_a*n_e, wealth fastest):
+//   primal record  [P][n_e][n_a] : s (EGM knots), kc (d s/d E), ib/A/B (bracket + tangent weights),
+//                                  u, v (marginal-value coefficients), pol (savings policy),
+//                                  lo/lw/ig (Young lottery), start (segment offsets), Dseq[P+1]
+//   tangent state  [n_e][n_a][N] : tangent index FASTEST (the AoS layout of Dual{T,V,N}): one grid
+//                                  point's N partials are one contiguous row, so the bracket gather
+//                                  and the lottery segment sums move whole coalesced rows.
+//   dpol           [P][n_e][n_a][N] : the policy-partials sequence BackwardIteration materialises
+//                                  (BackwardIteration.jl:88, :110-112); written once by the
+//                                  backward sweep, read once by the forward sweep = the
+//                                  algorithmic HBM traffic of a JVP batch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hank {
+
+constexpr int RBP = 32;        // rows (wealth points) per block in the primal kernels
+constexpr int TAN_THREADS = 256;
+constexpr int HEAVY = 48;      // lottery segments longer than this are summed by the whole block
+
+struct Consts {
+    int n_a, n_e, G, P;
+    double beta, gamma, bc;
+    const double *a, *z, *Pi;  // device
+};
+
+struct Record {
+    double *s, *kc, *A, *B, *u, *v, *pol, *lw, *ig, *Dseq;
+    int *ib, *lo, *start;
+};
+
+enum { ERR_KNOTS = 3, ERR_DOMAIN = 4, ERR_NONMONO = 6 };
+
+__device__ inline void set_err(int *err, int code, int t, int e, int j) {
+    if (atomicCAS(&err[0], 0, code) == 0) {
+        err[1] = t;
+        err[2] = e;
+        err[3] = j;
+    }
+}
+
+__device__ inline bool pow_domain_error(double v, double y) { return (v < 0.0) && (y != floor(y)); }
+
+// ---- block reductions (64-wide wavefronts) ------------------------------------------------
+__device__ inline double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+// sum over the whole block; result valid in thread 0; red must hold >= 16 doubles
+__device__ inline double block_sum(double x, double *red) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    x = wave_sum(x);
+    __syncthreads();
+    if (lane == 0) red[wv] = x;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < nw; k++) r += red[k];
+    return r;
+}
+
+// ---- EGM step, split in the two halves that fuse across the period boundary ------------------
+// X half (KrusellSmith.jl:59-62): from V_{t+1} (all e2 of this row, in LDS) to the endogenous
+// knot s_t[a,e] and kc = d s / d E  (= rho * d c / d E).
+__device__ inline void egm_X(const Consts &c, const double *Vsh, const double *Pish, int row, int a,
+                             int e, double r, double w, double *s_out, double *kc_out, int *err,
+                             int t) {
+    double E = Vsh[row] * Pish[e];
+    for (int e2 = 1; e2 < c.n_e; e2++) E += Vsh[e2 * RBP + row] * Pish[e + c.n_e * e2];
+    const double bE = E * c.beta;
+    const double ex = -1.0 / c.gamma;
+    if (pow_domain_error(bE, ex)) set_err(err, ERR_DOMAIN, t, e, a);
+    const double cm = pow(bE, ex);
+    const double rho = 1.0 / (1.0 + r);
+    *s_out = rho * ((cm - w * c.z[e]) + c.a[a]);
+    // d cmat/dE = beta*ex*(bE)^(ex-1)  (Dual^Real, ForwardDiff dual.jl:563-572)
+    *kc_out = rho * (c.beta * ex * (cm / bE));
+}
+
+// Y half (KrusellSmith.jl:66-80): interpolate the policy on the exogenous grid point a from the
+// knots of column e (sc = s_t[:,e]), apply the borrowing constraint, form the marginal value.
+// Interpolations.jl Gridded(Linear()) + Flat(): bracket = last knot <= x, flat outside.
+struct YOut {
+    double g, A, B, u, v, V;
+    int ib;
+};
+__device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, double r, double w,
+                             int *err, int t) {
+    YOut o;
+    const int n = c.n_a;
+    const double x = c.a[a];
+    const double sa = sc[a];
+    // Interpolations' check_gridded: knots must be sorted and unique (values)
+    if (a > 0 ? !(sa > sc[a - 1]) : !(sa == sa)) set_err(err, ERR_KNOTS, t, e, a);
+    const double s0 = sc[0], sN = sc[n - 1];
+    double g, A = 0.0, B = 0.0;
+    int i;
+    if (x < s0) {
+        g = c.a[0];
+        i = 0;
+    } else if (x > sN) {
+        g = c.a[n - 1];
+        i = n - 2;
+    } else {
+        int lo = -1, hi = n;  // sc[lo] <= x < sc[hi]
+        while (hi - lo > 1) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (sc[mid] <= x) lo = mid; else hi = mid;
+        }
+        i = lo < 0 ? 0 : (lo > n - 2 ? n - 2 : lo);
+        const double si = sc[i], sj = sc[i + 1];
+        const double h = sj - si;
+        const double f = (x - si) / h;
+        const double ai = c.a[i], aj = c.a[i + 1];
+        g = (1.0 - f) * ai + f * aj;
+        const double sl = (aj - ai) / h;
+        A = -sl * (1.0 - f);
+        B = -sl * f;
+    }
+    // max(g, borrow_cons), DiffRules rule: partial passes unless (bc > g) | signbit(bc) < signbit(g)
+    const double bc = c.bc;
+    if ((bc > g) || ((int)signbit(bc) < (int)signbit(g))) {
+        A = 0.0;
+        B = 0.0;
+    }
+    g = (g > bc) ? g : ((bc > g) ? bc : (signbit(g) ? bc : g));
+    const double opr = 1.0 + r;
+    const double cg = (opr * x + w * c.z[e]) - g;
+    if (pow_domain_error(cg, -c.gamma)) set_err(err, ERR_DOMAIN, t, e, a);
+    const double u = pow(cg, -c.gamma);
+    o.g = g;
+    o.A = A;
+    o.B = B;
+    o.ib = i;
+    o.u = u;
+    o.v = opr * ((-c.gamma) * (u / cg));
+    o.V = opr * u;
+    return o;
+}
+
+// block = RBP rows x n_e columns; thread (row, e) with row fastest. dynamic LDS:
+// Vsh[n_e*RBP] + Pish[n_e*n_e]
+__global__ void k_egm_X(Consts c, const double *Vin, const double *xt, double *s_out,
+                        double *kc_out, int *err, int t) {
+    extern __shared__ double sh[];
+    double *Vsh = sh, *Pish = sh + c.n_e * RBP;
+    const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
+    const int a = blockIdx.x * RBP + row;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    if (a < c.n_a) Vsh[e * RBP + row] = Vin[e * c.n_a + a];
+    __syncthreads();
+    if (a < c.n_a) egm_X(c, Vsh, Pish, row, a, e, xt[0], xt[1], &s_out[e * c.n_a + a], &kc_out[e * c.n_a + a], err, t);
+}
+
+// Y only (granular step): record slot pointers are for ONE period
+__global__ void k_egm_Y(Consts c, const double *s, double r, double w, double *pol, int *ib,
+                        double *A, double *B, double *u, double *v, double *Vout, int *err, int t) {
+    const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
+    const int a = blockIdx.x * RBP + row;
+    if (a >= c.n_a) return;
+    const YOut o = egm_Y(c, s + e * c.n_a, a, e, r, w, err, t);
+    const int off = e * c.n_a + a;
+    pol[off] = o.g; ib[off] = o.ib; A[off] = o.A; B[off] = o.B; u[off] = o.u; v[off] = o.v;
+    Vout[off] = o.V;
+}
+
+// fused sweep step: Y of period t, then X of period t-1 (value never leaves the CU)
+__global__ void k_egm_step(Consts c, Record R, const double *xhh, int t, int *err) {
+    extern __shared__ double sh[];
+    double *Vsh = sh, *Pish = sh + c.n_e * RBP;
+    const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
+    const int a = blockIdx.x * RBP + row;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    const size_t base = (size_t)t * c.G;
+    if (a < c.n_a) {
+        const double r = xhh[2 * t], w = xhh[2 * t + 1];
+        const YOut o = egm_Y(c, R.s + base + (size_t)e * c.n_a, a, e, r, w, err, t);
+        const size_t off = base + (size_t)e * c.n_a + a;
+        R.pol[off] = o.g; R.ib[off] = o.ib; R.A[off] = o.A; R.B[off] = o.B; R.u[off] = o.u; R.v[off] = o.v;
+        Vsh[e * RBP + row] = o.V;
+    }
+    __syncthreads();
+    if (t > 0 && a < c.n_a) {
+        const double r1 = xhh[2 * (t - 1)], w1 = xhh[2 * (t - 1) + 1];
+        const size_t off1 = base - c.G + (size_t)e * c.n_a + a;
+        egm_X(c, Vsh, Pish, row, a, e, r1, w1, &R.s[off1], &R.kc[off1], err, t - 1);
+    }
+}
+
+// ---- Young lottery for every (period, column) at once (ForwardIteration.jl:37-78) ------------
+// one block per column; builds lo / lw / ig and the segment offsets `start` that turn the
+// 2-nnz-per-column scatter into a deterministic gather (the policy is monotone in wealth).
+__global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
+    extern __shared__ int shlo[];
+    const int col = blockIdx.x;
+    if (col >= ncols) return;
+    const int t = col / c.n_e, e = col % c.n_e;
+    const size_t base = (size_t)col * c.n_a;  // == t*G + e*n_a
+    const int n = c.n_a;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const double p = R.pol[base + j];
+        int lo = -1, hi = n;  // grid[lo] < p <= grid[hi]  (searchsortedfirst, :52)
+        while (hi - lo > 1) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (c.a[mid] < p) lo = mid; else hi = mid;
+        }
+        int l;
+        double w, ig;
+        if (hi == 0) {            // m == 1: all mass on the first point (:54-58)
+            l = 0; w = 0.0; ig = 0.0;
+        } else if (hi >= n) {     // m > n_a: all mass on the last point (:59-63)
+            l = n - 2; w = 1.0; ig = 0.0;
+        } else {                  // interior (:64-73)
+            l = hi - 1;
+            const double gap = c.a[hi] - c.a[l];
+            w = (p - c.a[l]) / gap;
+            ig = 1.0 / gap;
+        }
+        R.lo[base + j] = l; R.lw[base + j] = w; R.ig[base + j] = ig;
+        shlo[j] = l;
+    }
+    __syncthreads();
+    int *st = R.start + (size_t)col * (n + 1);
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const int prev = j ? shlo[j - 1] : -1, cur = shlo[j];
+        if (cur < prev) set_err(err, ERR_NONMONO, t, e, j);
+        for (int r = prev + 1; r <= cur; r++) st[r] = j;
+        if (j == n - 1)
+            for (int r = cur + 1; r <= n; r++) st[r] = n;
+    }
+}
+
+// ---- distribution push-forward, one period (ForwardIteration.jl:95-99, :297-308) -------------
+// block = RBP rows x n_e; dynamic LDS: Dsh[n_e*RBP] + Pish[n_e*n_e] + red[16] + heavy list
+__global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
+    extern __shared__ double sh[];
+    double *Dsh = sh, *Pish = sh + c.n_e * RBP, *red = Pish + c.n_e * c.n_e;
+    __shared__ int nheavy;
+    __shared__ int heavy[64];
+    const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
+    const int r = blockIdx.x * RBP + row;
+    const int n = c.n_a;
+    if (threadIdx.x == 0) nheavy = 0;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    __syncthreads();
+    const double *Dprev = R.Dseq + (size_t)t * c.G;
+    const size_t base = (size_t)t * c.G;
+    double acc = 0.0;
+    if (r < n) {
+        const int *st = R.start + ((size_t)t * c.n_e + e) * (n + 1);
+        const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
+        bool mine = true;
+        if (st2 - st0 > HEAVY) {
+            const int slot = atomicAdd(&nheavy, 1);
+            if (slot < 64) { heavy[slot] = threadIdx.x; mine = false; }
+        }
+        if (mine) {
+            const double *lw = R.lw + base + (size_t)e * n, *Dp = Dprev + (size_t)e * n;
+            for (int j = st0; j < st1; j++) acc += lw[j] * Dp[j];
+            for (int j = st1; j < st2; j++) acc += (1.0 - lw[j]) * Dp[j];
+        }
+    }
+    __syncthreads();
+    const int nh = nheavy < 64 ? nheavy : 64;
+    for (int h = 0; h < nh; h++) {  // long segments (the borrowing-constraint mass point)
+        const int owner = heavy[h];
+        const int hrow = owner % RBP, he = owner / RBP, hr = blockIdx.x * RBP + hrow;
+        const int *st = R.start + ((size_t)t * c.n_e + he) * (n + 1);
+        const int st1 = st[hr], st2 = st[hr + 1], st0 = hr > 0 ? st[hr - 1] : st1;
+        const double *lw = R.lw + base + (size_t)he * n, *Dp = Dprev + (size_t)he * n;
+        double part = 0.0;
+        for (int j = st0 + threadIdx.x; j < st2; j += blockDim.x)
+            part += (j < st1 ? lw[j] : (1.0 - lw[j])) * Dp[j];
+        const double tot = block_sum(part, red);
+        if (threadIdx.x == 0) Dsh[he * RBP + hrow] = tot;
+        __syncthreads();
+        if (threadIdx.x == owner) acc = Dsh[he * RBP + hrow];
+        __syncthreads();
+    }
+    if (r < n) Dsh[e * RBP + row] = acc;
+    __syncthreads();
+    double part = 0.0;
+    if (r < n) {
+        const int e2 = e;  // D_new[r,e2] = sum_e D_mid[r,e] * Pi[e,e2]
+        double Dn = 0.0;
+        for (int k = 0; k < c.n_e; k++) Dn += Dsh[k * RBP + row] * Pish[k + c.n_e * e2];
+        R.Dseq[(size_t)(t + 1) * c.G + (size_t)e2 * n + r] = Dn;
+        part = R.pol[base + (size_t)e2 * n + r] * Dn;
+    }
+    const double tot = block_sum(part, red);
+    if (threadIdx.x == 0) aggpart[(size_t)t * gridDim.x + blockIdx.x] = tot;
+}
+
+// out[t*ncol + n] = sum_b parts[(t*nb + b)*ncol + n]   (fixed order: bitwise reproducible)
+__global__ void k_reduce_parts(const double *parts, int nb, int ncol, int total, double *out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int t = idx / ncol, n = idx - t * ncol;
+    const double *p = parts + (size_t)t * nb * ncol + n;
+    double s = 0.0;
+    for (int b = 0; b < nb; b++) s += p[(size_t)b * ncol];
+    out[idx] = s;
+}
+
+// ---- tangent sweeps ------------------------------------------------------------------------
+// thread <-> (wealth row a, tangent n); loops over the NE productivity columns so the n_e x n_e
+// mixing is register-local. NC = tangents per block row (power of two), RB = 256/NC rows.
+struct TanGeom { int N, NC, lgNC; };
+
+// (n_hh, P, N) column-major  ->  dxr[P][N], dxw[P][N]
+__global__ void k_tan_in(const double *dxhh, int P, int N, double *dxr, double *dxw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P * N) return;
+    const int t = idx / N, n = idx - t * N;
+    dxr[idx] = dxhh[0 + 2 * ((size_t)t + (size_t)P * n)];
+    dxw[idx] = dxhh[1 + 2 * ((size_t)t + (size_t)P * n)];
+}
+// dagg[P][N] -> (P, N) column-major
+__global__ void k_tan_out(const double *dagg, int P, int N, double *out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P * N) return;
+    const int n = idx / P, t = idx - n * P;
+    out[idx] = dagg[(size_t)t * N + n];
+}
+
+// knot tangents of the last period: dV_T = 0 (terminal value has zero partials,
+// BackwardIteration.jl:85) => ds = -rho*(z_e*dw + s*dr)
+__global__ void k_tan_back_init(Consts c, Record R, const double *xhh, const double *dxr,
+                                const double *dxw, TanGeom g, int t, double *dsOut) {
+    const int nl = threadIdx.x & (g.NC - 1), rl = threadIdx.x >> g.lgNC;
+    const int a = blockIdx.x * (TAN_THREADS >> g.lgNC) + rl, n = blockIdx.y * g.NC + nl;
+    if (a >= c.n_a || n >= g.N) return;
+    const double rho = 1.0 / (1.0 + xhh[2 * t]);
+    const double dr = dxr[(size_t)t * g.N + n], dw = dxw[(size_t)t * g.N + n];
+    for (int e = 0; e < c.n_e; e++) {
+        const size_t off = (size_t)t * c.G + (size_t)e * c.n_a + a;
+        dsOut[((size_t)e * c.n_a + a) * g.N + n] = -rho * (c.z[e] * dw + R.s[off] * dr);
+    }
+}
+
+// one backward period: Y-tangent of period t (bracket gather -> dpol_t, dV_t), then X-tangent of
+// period t-1 (mix over e -> knot tangents). dsIn/dsOut ping-pong in L2 / Infinity Cache.
+template <int NE>
+__global__ void __launch_bounds__(TAN_THREADS)
+k_tan_back(Consts c, Record R, const double *xhh, const double *dxr, const double *dxw, TanGeom g,
+           int t, const double *dsIn, double *dsOut, double *dpol) {
+    const int nl = threadIdx.x & (g.NC - 1), rl = threadIdx.x >> g.lgNC;
+    const int a = blockIdx.x * (TAN_THREADS >> g.lgNC) + rl, n = blockIdx.y * g.NC + nl;
+    if (a >= c.n_a || n >= g.N) return;
+    const size_t N = g.N;
+    const double dr = dxr[(size_t)t * N + n], dw = dxw[(size_t)t * N + n];
+    const double xa = c.a[a];
+    double dV[NE];
+    const size_t base = (size_t)t * c.G;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const size_t off = base + (size_t)e * c.n_a + a;
+        const int i = R.ib[off];
+        const double A = R.A[off], B = R.B[off];
+        const double *col = dsIn + ((size_t)e * c.n_a) * N + n;
+        const double dg = A * col[(size_t)i * N] + B * col[(size_t)(i + 1) * N];
+        dpol[off * N + n] = dg;
+        dV[e] = R.u[off] * dr + R.v[off] * ((xa * dr + c.z[e] * dw) - dg);
+    }
+    if (t == 0) return;
+    const double rho1 = 1.0 / (1.0 + xhh[2 * (t - 1)]);
+    const double dr1 = dxr[(size_t)(t - 1) * N + n], dw1 = dxw[(size_t)(t - 1) * N + n];
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        double dE = dV[0] * c.Pi[e];
+#pragma unroll
+        for (int e2 = 1; e2 < NE; e2++) dE += dV[e2] * c.Pi[e + NE * e2];
+        const size_t off1 = base - c.G + (size_t)e * c.n_a + a;
+        dsOut[((size_t)e * c.n_a + a) * N + n] = R.kc[off1] * dE - rho1 * (c.z[e] * dw1 + R.s[off1] * dr1);
+    }
+}
+
+// one forward period: segment gather of the lottery tangent, mix over e, aggregate.
+// dagg_t = sum( dpol_t * D_t + pol_t * dD_t ) with the POST-transition D_t.
+template <int NE>
+__global__ void __launch_bounds__(TAN_THREADS)
+k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *dDin, double *dDout,
+          const double *dpol, double *aggpart) {
+    __shared__ double red[TAN_THREADS];
+    const int nl = threadIdx.x & (g.NC - 1), rl = threadIdx.x >> g.lgNC;
+    const int RB = TAN_THREADS >> g.lgNC;
+    const int r = blockIdx.x * RB + rl, n = blockIdx.y * g.NC + nl;
+    const size_t N = g.N;
+    const int na = c.n_a;
+    double part = 0.0;
+    if (r < na && n < g.N) {
+        const size_t base = (size_t)t * c.G;
+        const double *Dprev = R.Dseq + base, *Dnew = R.Dseq + base + c.G;
+        double acc[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int *st = R.start + ((size_t)t * NE + e) * (na + 1);
+            const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
+            const size_t cb = base + (size_t)e * na;
+            const double *dDc = dDin + ((size_t)e * na) * N + n;
+            const double *dpc = dpol + cb * N + n;
+            double s = 0.0;
+            for (int j = st0; j < st1; j++)
+                s += R.lw[cb + j] * dDc[(size_t)j * N] + (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[(size_t)e * na + j];
+            for (int j = st1; j < st2; j++)
+                s += (1.0 - R.lw[cb + j]) * dDc[(size_t)j * N] - (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[(size_t)e * na + j];
+            acc[e] = s;
+        }
+#pragma unroll
+        for (int e2 = 0; e2 < NE; e2++) {
+            double dDn = acc[0] * c.Pi[NE * e2];
+#pragma unroll
+            for (int e = 1; e < NE; e++) dDn += acc[e] * c.Pi[e + NE * e2];
+            const size_t off = base + (size_t)e2 * na + r;
+            dDout[((size_t)e2 * na + r) * N + n] = dDn;
+            part += R.pol[off] * dDn + dpol[off * N + n] * Dnew[(size_t)e2 * na + r];
+        }
+    }
+    // sum over the RB rows of this block for each tangent lane
+    red[threadIdx.x] = part;
+    __syncthreads();
+    if (threadIdx.x < g.NC) {
+        double s = 0.0;
+        for (int k = 0; k < RB; k++) s += red[k * g.NC + threadIdx.x];
+        const int nn = blockIdx.y * g.NC + threadIdx.x;
+        if (nn < g.N) aggpart[((size_t)t * gridDim.x + blockIdx.x) * N + nn] = s;
+    }
+}
+
+// ---- granular tangent halves (hank_backward_step_dual) ---------------------------------------
+// X-tangent alone: dV' (G,N col-major) -> ds[e][a][N]
+__global__ void k_tan_X(Consts c, const double *kc, const double *s, double r, const double *dr,
+                        const double *dw, int N, const double *dVin_colmajor, double *dsOut) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= c.G * N) return;
+    const int n = idx % N, pt = idx / N, e = pt / c.n_a, a = pt - e * c.n_a;
+    double dE = 0.0;
+    for (int e2 = 0; e2 < c.n_e; e2++) dE += dVin_colmajor[(size_t)n * c.G + (size_t)e2 * c.n_a + a] * c.Pi[e + c.n_e * e2];
+    const double rho = 1.0 / (1.0 + r);
+    dsOut[(size_t)pt * N + n] = kc[pt] * dE - rho * (c.z[e] * dw[n] + s[pt] * dr[n]);
+}
+// Y-tangent alone: ds -> dpol, dV (both (G,N) col-major for the caller)
+__global__ void k_tan_Y(Consts c, const int *ib, const double *A, const double *B, const double *u,
+                        const double *v, const double *dr, const double *dw, int N,
+                        const double *ds, double *dpol_cm, double *dV_cm) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= c.G * N) return;
+    const int n = idx % N, pt = idx / N, e = pt / c.n_a, a = pt - e * c.n_a;
+    const int i = ib[pt];
+    const double *col = ds + ((size_t)e * c.n_a) * N + n;
+    const double dg = A[pt] * col[(size_t)i * N] + B[pt] * col[(size_t)(i + 1) * N];
+    dpol_cm[(size_t)n * c.G + pt] = dg;
+    dV_cm[(size_t)n * c.G + pt] = u[pt] * dr[n] + v[pt] * ((c.a[a] * dr[n] + c.z[e] * dw[n]) - dg);
+}
+
+// ---- granular forward step for ARBITRARY policies (atomic scatter; parity tests of a6/a7) -----
+// Dmid [G*(1+N)]: slot 0 = value, slots 1..N = partials, layout [pt][1+N]
+__global__ void k_scatter_general(Consts c, const double *policy, const double *dpolicy_cm,
+                                  const double *Dprev, const double *dDprev_cm, int N, double *Dmid) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = 1 + N;
+    if (idx >= c.G * W) return;
+    const int k = idx % W, pt = idx / W, e = pt / c.n_a;
+    const int n = c.n_a;
+    const double p = policy[pt];
+    int lo = -1, hi = n;
+    while (hi - lo > 1) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (c.a[mid] < p) lo = mid; else hi = mid;
+    }
+    const double Dv = Dprev[pt];
+    const double dD = k ? dDprev_cm[(size_t)(k - 1) * c.G + pt] : 0.0;
+    const double val = k ? dD : Dv;  // the slot's "D"
+    if (hi == 0) {
+        atomicAdd(&Dmid[((size_t)e * n + 0) * W + k], val);
+    } else if (hi >= n) {
+        atomicAdd(&Dmid[((size_t)e * n + n - 1) * W + k], val);
+    } else {
+        const int l = hi - 1;
+        const double gap = c.a[hi] - c.a[l];
+        const double w = (p - c.a[l]) / gap;
+        if (k == 0) {
+            atomicAdd(&Dmid[((size_t)e * n + l) * W], (1.0 - w) * Dv);
+            atomicAdd(&Dmid[((size_t)e * n + hi) * W], w * Dv);
+        } else {
+            const double dwt = dpolicy_cm[(size_t)(k - 1) * c.G + pt] / gap;
+            atomicAdd(&Dmid[((size_t)e * n + l) * W + k], (1.0 - w) * dD - dwt * Dv);
+            atomicAdd(&Dmid[((size_t)e * n + hi) * W + k], w * dD + dwt * Dv);
+        }
+    }
+}
+// mix over e + per-point aggregate terms; outputs col-major (G) and (G,N); aggterm[pt*(1+N)+k]
+__global__ void k_mix_general(Consts c, const double *Dmid, const double *policy,
+                              const double *dpolicy_cm, int N, double *Dout, double *dDout_cm,
+                              double *aggterm) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = 1 + N;
+    if (idx >= c.G * W) return;
+    const int k = idx % W, pt = idx / W, e2 = pt / c.n_a, a = pt - e2 * c.n_a;
+    double s = 0.0;
+    for (int e = 0; e < c.n_e; e++) s += Dmid[((size_t)e * c.n_a + a) * W + k] * c.Pi[e + c.n_e * e2];
+    if (k == 0) {
+        Dout[pt] = s;
+        aggterm[(size_t)pt * W] = policy[pt] * s;
+    } else {
+        dDout_cm[(size_t)(k - 1) * c.G + pt] = s;
+        double Dn = 0.0;
+        for (int e = 0; e < c.n_e; e++) Dn += Dmid[((size_t)e * c.n_a + a) * W] * c.Pi[e + c.n_e * e2];
+        aggterm[(size_t)pt * W + k] = policy[pt] * s + dpolicy_cm[(size_t)(k - 1) * c.G + pt] * Dn;
+    }
+}
+// out[k] = sum_pt aggterm[pt*W + k], one block per k (fixed order within the block tree)
+__global__ void k_colsum(const double *aggterm, int G, int W, double *out) {
+    __shared__ double red[16];
+    const int k = blockIdx.x;
+    double s = 0.0;
+    for (int pt = threadIdx.x; pt < G; pt += blockDim.x) s += aggterm[(size_t)pt * W + k];
+    const double tot = block_sum(s, red);
+    if (threadIdx.x == 0) out[k] = tot;
+}
+
+// (G,P,N) col-major export of dpol[P][G][N]
+__global__ void k_export_dpol(const double *dpol, int G, int P, int N, double *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)G * P * N;
+    if (idx >= total) return;
+    const size_t n = idx / ((size_t)G * P), rem = idx - n * (size_t)G * P, t = rem / G, pt = rem - t * G;
+    out[idx] = dpol[(t * G + pt) * N + n];
+}
+
+}  // namespace hank

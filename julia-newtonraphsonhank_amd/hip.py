@@ -1,0 +1,267 @@
+"""ctypes binding of the C ABI in include/hank_hip.h (libhank_hip.so, hand-written HIP for gfx950).
+
+There is no CPU fallback on this path: if the shared library is missing or no MI355X is usable the
+constructors raise — the product never silently computes the household block anywhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "libhank_hip.so"
+_lib = None
+
+HANK_OK = 0
+HANK_ERR_NO_DEVICE, HANK_ERR_BAD_ARG, HANK_ERR_KNOTS, HANK_ERR_DOMAIN = 1, 2, 3, 4
+HANK_ERR_NOT_READY, HANK_ERR_NONMONOTONE, HANK_ERR_NOMEM = 5, 6, 7
+HANK_VF_KRUSELL_SMITH = 0
+
+# the symbols include/hank_hip.h declares (tests check that every one is exported)
+ABI_SYMBOLS = (
+    "hank_create", "hank_destroy", "hank_last_error", "hank_n_hh", "hank_set_stream", "hank_sync",
+    "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
+    "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
+    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings",
+)
+
+
+class HankHIPError(RuntimeError):
+    """Base class: a non-zero status from libhank_hip (message = hank_last_error)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[hank_hip status {code}] {msg}")
+        self.code = code
+
+
+class KnotsNotSortedError(HankHIPError):
+    """Interpolations.jl's 'knot-vectors must be unique and sorted' (KrusellSmith.jl:69-72)."""
+
+
+class DomainError(HankHIPError):
+    """Julia's DomainError: negative base under a non-integer power (KrusellSmith.jl:59, :80)."""
+
+
+class NoDeviceError(HankHIPError):
+    """No usable gfx950 device / HIP runtime failure."""
+
+
+_ERR_CLASSES = {HANK_ERR_KNOTS: KnotsNotSortedError, HANK_ERR_DOMAIN: DomainError,
+                HANK_ERR_NO_DEVICE: NoDeviceError}
+
+
+class hank_model(C.Structure):
+    _fields_ = [("n_a", C.c_int32), ("n_e", C.c_int32), ("T", C.c_int32), ("value_fn_id", C.c_int32),
+                ("a_grid", C.POINTER(C.c_double)), ("z_grid", C.POINTER(C.c_double)),
+                ("Pi", C.POINTER(C.c_double)),
+                ("beta", C.c_double), ("gamma", C.c_double), ("borrow_cons", C.c_double)]
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """dlopen libhank_hip.so (built by __graft_entry__.build() / csrc/Makefile). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(str(_LIB_PATH))
+    dp, vp, i32 = C.POINTER(C.c_double), C.c_void_p, C.c_int32
+    lib.hank_create.argtypes = [C.POINTER(hank_model), C.POINTER(vp)]
+    lib.hank_destroy.argtypes = [vp]
+    lib.hank_last_error.argtypes = [vp]
+    lib.hank_last_error.restype = C.c_char_p
+    lib.hank_n_hh.argtypes = [vp]
+    lib.hank_set_stream.argtypes = [vp, vp]
+    lib.hank_sync.argtypes = [vp]
+    lib.hank_set_boundary.argtypes = [vp, dp, dp]
+    lib.hank_primal.argtypes = [vp, dp, dp]
+    lib.hank_jvp.argtypes = [vp, dp, i32, dp]
+    lib.hank_primal_dev.argtypes = [vp, vp, vp]
+    lib.hank_jvp_dev.argtypes = [vp, vp, i32, vp]
+    lib.hank_check.argtypes = [vp]
+    lib.hank_get_policy_seq.argtypes = [vp, dp]
+    lib.hank_get_dpolicy_seq.argtypes = [vp, i32, dp]
+    lib.hank_get_dist_seq.argtypes = [vp, dp]
+    lib.hank_backward_step.argtypes = [vp, dp, dp, dp, dp]
+    lib.hank_backward_step_dual.argtypes = [vp, dp, dp, dp, dp, i32, dp, dp, dp, dp]
+    lib.hank_forward_step.argtypes = [vp, dp, dp, dp, dp]
+    lib.hank_forward_step_dual.argtypes = [vp, dp, dp, dp, dp, i32, dp, dp, dp, dp]
+    lib.hank_last_timings.argtypes = [vp, dp, C.POINTER(i32)]
+    for name in ABI_SYMBOLS:
+        if name != "hank_last_error":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _f(x, shape=None) -> np.ndarray:
+    """contiguous column-major float64 copy (Julia's memory layout), optionally shape-checked."""
+    arr = np.asfortranarray(np.asarray(x, dtype=np.float64))
+    if shape is not None and tuple(arr.shape) != tuple(shape):
+        raise ValueError(f"expected array of shape {tuple(shape)}, got {tuple(arr.shape)}")
+    return arr
+
+
+def _p(arr: np.ndarray):
+    return arr.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class HouseholdBlock:
+    """One hank_ctx: the device-resident household block of a SequenceModel.
+
+    Mirrors what `BackwardIteration` / `ForwardIteration` read from `model` (grids, Π, β, γ,
+    borrow_cons, T; GeneralStructures.jl:216-226) and from `ss_end` / `ss_initial`.
+    All matrices are (n_a, n_e); numpy arrays of that shape are accepted in any memory order.
+    """
+
+    def __init__(self, a_grid, z_grid, Pi, beta, gamma, borrow_cons, T, value_fn_id=HANK_VF_KRUSELL_SMITH):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        self.a_grid = np.ascontiguousarray(a_grid, dtype=np.float64)
+        self.z_grid = np.ascontiguousarray(z_grid, dtype=np.float64)
+        self.n_a, self.n_e = self.a_grid.size, self.z_grid.size
+        self.Pi = _f(Pi, (self.n_e, self.n_e))
+        self.T, self.P, self.G = int(T), int(T) - 1, self.n_a * self.n_e
+        m = hank_model(self.n_a, self.n_e, self.T, value_fn_id, _p(self.a_grid), _p(self.z_grid),
+                       _p(self.Pi), float(beta), float(gamma), float(borrow_cons))
+        rc = self._lib.hank_create(C.byref(m), C.byref(self._ctx))
+        if rc != HANK_OK:
+            msg = self._lib.hank_last_error(self._ctx).decode() if self._ctx else "hank_create failed"
+            if not msg and rc == HANK_ERR_NO_DEVICE:
+                msg = "no HIP device available"
+            if self._ctx:
+                self._lib.hank_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+            raise _ERR_CLASSES.get(rc, HankHIPError)(rc, msg or "no HIP device available (gfx950 required)")
+        self.n_hh = self._lib.hank_n_hh(self._ctx)
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != HANK_OK:
+            raise _ERR_CLASSES.get(rc, HankHIPError)(rc, self._lib.hank_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.hank_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream_handle: int | None):
+        self._chk(self._lib.hank_set_stream(self._ctx, C.c_void_p(hip_stream_handle or 0)))
+
+    def sync(self):
+        self._chk(self._lib.hank_sync(self._ctx))
+
+    def check(self):
+        self._chk(self._lib.hank_check(self._ctx))
+
+    # -- boundary + fused sweeps ------------------------------------------------------------
+    def set_boundary(self, ss_end_value, ss_init_D):
+        v = _f(ss_end_value, (self.n_a, self.n_e))
+        d = _f(np.asarray(ss_init_D, dtype=np.float64).reshape((self.n_a, self.n_e), order="F"))
+        self._chk(self._lib.hank_set_boundary(self._ctx, _p(v), _p(d)))
+
+    def primal(self, xhh) -> np.ndarray:
+        x = _f(xhh, (self.n_hh, self.P))
+        agg = np.empty(self.P)
+        self._chk(self._lib.hank_primal(self._ctx, _p(x), _p(agg)))
+        return agg
+
+    def jvp(self, dxhh) -> np.ndarray:
+        dx = np.asarray(dxhh, dtype=np.float64)
+        if dx.ndim == 2:
+            dx = dx[:, :, None]
+        N = dx.shape[2]
+        dx = _f(dx, (self.n_hh, self.P, N))
+        out = np.empty((self.P, N), order="F")
+        self._chk(self._lib.hank_jvp(self._ctx, _p(dx), N, _p(out)))
+        return out
+
+    def primal_dev(self, d_xhh_ptr: int, d_agg_ptr: int = 0):
+        self._chk(self._lib.hank_primal_dev(self._ctx, C.c_void_p(d_xhh_ptr), C.c_void_p(d_agg_ptr)))
+
+    def jvp_dev(self, d_dxhh_ptr: int, N: int, d_dagg_ptr: int = 0):
+        self._chk(self._lib.hank_jvp_dev(self._ctx, C.c_void_p(d_dxhh_ptr), int(N), C.c_void_p(d_dagg_ptr)))
+
+    def last_timings(self):
+        ms = (C.c_double * 4)()
+        ln = (C.c_int32 * 4)()
+        self._chk(self._lib.hank_last_timings(self._ctx, ms, ln))
+        names = ("primal_backward", "primal_forward", "tangent_backward", "tangent_forward")
+        return {k: {"ms": ms[i], "launches": ln[i]} for i, k in enumerate(names)}
+
+    def policy_seq(self) -> np.ndarray:
+        """(n_a, n_e, P): policy matrix of every period (BackwardIteration's return value)."""
+        out = np.empty((self.n_a, self.n_e, self.P), order="F")
+        self._chk(self._lib.hank_get_policy_seq(self._ctx, _p(out)))
+        return out
+
+    def dist_seq(self) -> np.ndarray:
+        out = np.empty((self.n_a, self.n_e, self.P), order="F")
+        self._chk(self._lib.hank_get_dist_seq(self._ctx, _p(out)))
+        return out
+
+    def dpolicy_seq(self, N: int) -> np.ndarray:
+        """(n_a, n_e, P, N): partials of the policy sequence of the last jvp."""
+        out = np.empty((self.n_a, self.n_e, self.P, N), order="F")
+        self._chk(self._lib.hank_get_dpolicy_seq(self._ctx, int(N), _p(out)))
+        return out
+
+    # -- granular steps ---------------------------------------------------------------------
+    def backward_step(self, value_next, xhh_t):
+        v = _f(value_next, (self.n_a, self.n_e))
+        x = _f(xhh_t, (self.n_hh,))
+        vo = np.empty((self.n_a, self.n_e), order="F")
+        po = np.empty((self.n_a, self.n_e), order="F")
+        self._chk(self._lib.hank_backward_step(self._ctx, _p(v), _p(x), _p(vo), _p(po)))
+        return vo, po
+
+    def backward_step_dual(self, value_next, dvalue_next, xhh_t, dxhh_t):
+        dv = np.asarray(dvalue_next, dtype=np.float64)
+        N = dv.shape[-1]
+        v = _f(value_next, (self.n_a, self.n_e))
+        dv = _f(dv, (self.n_a, self.n_e, N))
+        x = _f(xhh_t, (self.n_hh,))
+        dx = _f(dxhh_t, (self.n_hh, N))
+        vo = np.empty((self.n_a, self.n_e), order="F")
+        po = np.empty((self.n_a, self.n_e), order="F")
+        dvo = np.empty((self.n_a, self.n_e, N), order="F")
+        dpo = np.empty((self.n_a, self.n_e, N), order="F")
+        self._chk(self._lib.hank_backward_step_dual(self._ctx, _p(v), _p(dv), _p(x), _p(dx), N,
+                                                    _p(vo), _p(dvo), _p(po), _p(dpo)))
+        return vo, dvo, po, dpo
+
+    def forward_step(self, policy, D_prev):
+        p = _f(policy, (self.n_a, self.n_e))
+        d = _f(np.asarray(D_prev, dtype=np.float64).reshape((self.n_a, self.n_e), order="F"))
+        do = np.empty((self.n_a, self.n_e), order="F")
+        agg = C.c_double()
+        self._chk(self._lib.hank_forward_step(self._ctx, _p(p), _p(d), _p(do), C.byref(agg)))
+        return do, agg.value
+
+    def forward_step_dual(self, policy, dpolicy, D_prev, dD_prev):
+        dp_ = np.asarray(dpolicy, dtype=np.float64)
+        N = dp_.shape[-1]
+        p = _f(policy, (self.n_a, self.n_e))
+        dp_ = _f(dp_, (self.n_a, self.n_e, N))
+        d = _f(np.asarray(D_prev, dtype=np.float64).reshape((self.n_a, self.n_e), order="F"))
+        dd = _f(np.asarray(dD_prev, dtype=np.float64).reshape((self.n_a, self.n_e, N), order="F"))
+        do = np.empty((self.n_a, self.n_e), order="F")
+        ddo = np.empty((self.n_a, self.n_e, N), order="F")
+        agg = C.c_double()
+        dagg = np.empty(N)
+        self._chk(self._lib.hank_forward_step_dual(self._ctx, _p(p), _p(dp_), _p(d), _p(dd), N,
+                                                   _p(do), _p(ddo), C.byref(agg), _p(dagg)))
+        return do, ddo, agg.value, dagg

@@ -1,0 +1,43 @@
+"""Tangent-batch sharding across the GPUs of one node.
+
+Tangent directions are independent given the primal (a JVP is linear in the tangent,
+GeneralStructures.jl:546), so rank g takes columns [g·N/W, (g+1)·N/W) of the tangent matrix, every
+rank runs the (cheap) primal sweep redundantly, and ONE all-gather of the n x N/W result blocks
+assembles J·Y on every rank (RCCL over xGMI when the process group is "nccl"; "gloo" in CPU tests).
+There is no other collective on the path.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(N: int, world_size: int, rank: int):
+    """contiguous near-equal column ranges; the first N % W ranks get one extra column."""
+    base, extra = divmod(N, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def sharded_jvp(jvp_fn: Callable[[torch.Tensor], torch.Tensor], tangents: torch.Tensor, group=None) -> torch.Tensor:
+    """jvp_fn maps an (n, k) tangent block to the (m, k) block J·Y_k on this rank's device.
+    Returns the full (m, N) product on every rank."""
+    W = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    N = tangents.shape[1]
+    lo, hi = shard_bounds(N, W, rank)
+    local = jvp_fn(tangents[:, lo:hi])
+    if W == 1:
+        return local
+    m = local.shape[0]
+    if N % W == 0:
+        # equal shards: one all_gather_into_tensor of (k, m) row blocks (columns of J·Y are rows here)
+        out = torch.empty((N, m), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.t().contiguous(), group=group)
+        return out.t()
+    parts = [torch.empty((shard_bounds(N, W, r)[1] - shard_bounds(N, W, r)[0], m), dtype=local.dtype, device=local.device)
+             for r in range(W)]
+    dist.all_gather(parts, local.t().contiguous(), group=group)
+    return torch.cat(parts, dim=0).t()

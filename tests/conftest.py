@@ -1,0 +1,64 @@
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hank():
+    import hank_amd
+    return hank_amd
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+_SS_CACHE = {}
+
+
+def ks_setup(n_a, n_e, T):
+    """model + steady state + oracle for a Krusell-Smith economy of the given size (cached)."""
+    key = (n_a, n_e, T)
+    if key not in _SS_CACHE:
+        import hank_amd as h
+        from oracle.oracle import Oracle
+        ov = {"T": T, "dimensions": {"wealth": {"n": n_a}, "productivity": {"n": n_e}}}
+        m = h.build_model_from_yaml(str(ROOT / "examples" / "krusell_smith.yaml"), overrides=ov)
+        ss, _ = h.get_SteadyStates(m)
+        wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+        orc = Oracle(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons)
+        _SS_CACHE[key] = (m, ss, orc)
+    return _SS_CACHE[key]
+
+
+def ks_paths(m, ss, kind="x1", shock=0.01):
+    """primal points of BASELINE.md §3: x0 = SS repeated; x1 = firm conditions at fixed SS capital
+    under Z_t = 1 + shock*0.8^t (non-stationary, exercises moving brackets)."""
+    P = m.compspec.T - 1
+    α, δ = m.params.α, m.params.δ
+    t = np.arange(1, P + 1)
+    Z = 1.0 + shock * 0.8 ** t
+    K = ss.vars["KS"]
+    if kind == "x0":
+        x = np.tile(np.array([ss.vars[k] for k in ("Y", "KS", "r", "w")])[:, None], (1, P))
+    else:
+        x = np.stack([Z * K ** α, np.full(P, K), α * Z * K ** (α - 1) - δ, (1 - α) * Z * K ** α])
+    return x, Z
+
+
+@pytest.fixture(scope="session")
+def ks_small():
+    return ks_setup(50, 2, 100)
