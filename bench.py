@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py — sequence-space JVPs/sec of the MI355X household block (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input: the primal sweep at x
+(BackwardIteration + ForwardIteration on Float64, recorded once) followed by ONE batched JVP of N
+tangent directions through the same two sweeps. Inputs (x, tangents, boundary) are resident in HBM
+before the timed region starts. Default workload = BASELINE.json configs[2]: Krusell–Smith
+2000x11 grid, T=300, 32-wide tangent batch on 1 GPU (the configuration the north star's target is
+quoted on; configs[1] — 500x4, single tangent — is latency-bound and is reported in `extra`).
+
+N>1 GPUs: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; tangent
+columns shard across ranks (32 per GPU, weak scaling), every rank runs the primal redundantly, one
+RCCL all-gather per step assembles the P x (32·N) aggregate-tangent block on every rank.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+WORKLOADS = {
+    "ks_2000x11_T300_N32": dict(n_a=2000, n_e=11, T=300, N=32),   # BASELINE.json configs[2]
+    "ks_500x4_T300_N1": dict(n_a=500, n_e=4, T=300, N=1),          # configs[1]
+    "ks_50x2_T100_N1": dict(n_a=50, n_e=2, T=100, N=1),            # configs[0] (plumbing)
+}
+
+
+def load_or_solve_ss(n_a, n_e, T):
+    """model + steady state; the 2000x11 steady state (64 s of host Newton) is cached as a fixture."""
+    import hank_amd as h
+    from conftest import ks_setup
+    fx = ROOT / "examples" / "fixtures" / f"ks_ss_{n_a}x{n_e}.npz"
+    if fx.exists():
+        ov = {"T": T, "dimensions": {"wealth": {"n": n_a}, "productivity": {"n": n_e}}}
+        m = h.build_model_from_yaml(str(ROOT / "examples" / "krusell_smith.yaml"), overrides=ov)
+        g = np.load(fx)
+        if np.array_equal(g["a_grid"], m.heterogeneity["wealth"].grid) and np.array_equal(g["Pi"], m.heterogeneity["productivity"].transition):
+            ss = h.SteadyState({k: float(g[f"var_{k}"]) for k in m.variables}, {"KD": g["policy"]}, None, g["D"], g["value"])
+            return m, ss
+    m, ss, _ = ks_setup(n_a, n_e, T)
+    return m, ss
+
+
+def cpu_baseline(m, ss, x, Z, budget_s=12.0):
+    """the reference-style CPU path (oracle: dual numbers, primal recomputed on every JVP,
+    NewtonRaphson.jl:95) timed on ONE host core on a bounded sample of the same workload."""
+    from oracle.oracle import Oracle
+    wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    orc = Oracle(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons)
+    P = m.compspec.T - 1
+    rng = np.random.default_rng(1)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        y = rng.standard_normal((4, P, 1))
+        orc.ks_jvp(x, y, Z, m.params.α, m.params.δ, ss.vars["KS"], ss.value, ss.D)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 64:
+            break
+    return {"value": n / el, "unit": "JVPs/s", "cores": 1, "kind": "port",
+            "sample": f"{n} single-tangent JVPs (dual-number pipeline incl. primal, {m.heterogeneity['wealth'].n}x"
+                      f"{m.heterogeneity['productivity'].n} grid, T={m.compspec.T}) in {el:.1f} s on 1 core"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ks_2000x11_T300_N32", choices=sorted(WORKLOADS))
+    ap.add_argument("--tangents", type=int, default=None, help="override the per-GPU tangent batch width")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import hank_amd as h
+    from conftest import ks_paths
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.tangents:
+        wl["N"] = args.tangents
+    n_a, n_e, T, N = wl["n_a"], wl["n_e"], wl["T"], wl["N"]
+    P, G = T - 1, n_a * n_e
+    m, ss = load_or_solve_ss(n_a, n_e, T)
+    x, Z = ks_paths(m, ss, "x1", 0.01)
+
+    hb = h.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    # synthetic inputs, resident in HBM: household inputs (r_t, w_t) and this rank's tangent columns
+    rng = np.random.default_rng(1000 + rank)
+    d_x = torch.from_numpy(np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()).to(dev)
+    d_dx = torch.from_numpy(rng.standard_normal(2 * P * N)).to(dev)     # (2, P, N) column-major
+    d_agg = torch.empty(P, dtype=torch.float64, device=dev)
+    d_dagg = torch.empty(P * N, dtype=torch.float64, device=dev)        # (P, N) column-major
+    d_all = torch.empty(world * P * N, dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
+        hb.jvp_dev(d_dx.data_ptr(), N, d_dagg.data_ptr())
+        if world > 1:
+            hb.sync()                                   # library stream -> RCCL stream hand-over
+            dist.all_gather_into_tensor(d_all, d_dagg)  # the only exchange on the path
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    hb.check()
+    fence()
+    t0 = time.perf_counter()
+    sweeps = {k: 0.0 for k in ("primal_backward", "primal_forward", "tangent_backward", "tangent_forward")}
+    for _ in range(args.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    hb.check()
+    tm = hb.last_timings()          # HIP events on the library's stream around each sweep (last step)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # live per-sweep device times over a few extra (untimed) steps, for the roofline object
+    reps = 5
+    acc = {k: 0.0 for k in sweeps}
+    for _ in range(reps):
+        hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
+        hb.jvp_dev(d_dx.data_ptr(), N, d_dagg.data_ptr())
+        tmi = hb.last_timings()
+        for k in acc:
+            acc[k] += tmi[k]["ms"] / reps
+    launches = {k: tm[k]["launches"] for k in tm}
+
+    if rank == 0:
+        total_jvps = world * N * args.steps
+        ms_per_step = 1e3 * el / args.steps
+        # dominant kernel: the per-period tangent kernels (k_tan_back / k_tan_fwd). One launch moves
+        # the policy partials of ONE period for N directions: G*8*N algorithmic bytes
+        # (B_alg = 2*P*G*8*(1+N) per batch = G*8 bytes per (sweep, period, direction)).
+        dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
+        kname = {"tangent_backward": "k_tan_back", "tangent_forward": "k_tan_fwd"}[dom]
+        bytes_per_launch = G * 8 * N
+        avg_launch_s = 1e-3 * acc[dom] / launches[dom]
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        pmc = None
+        pmc_file = ROOT / "profiles" / "pmc_latest.json"
+        if pmc_file.exists():
+            try:
+                pmc = json.loads(pmc_file.read_text()).get(args.workload, {}).get(kname)
+            except Exception:
+                pmc = None
+        b_alg_batch = 2 * P * G * 8 * (1 + N)
+        out = {
+            "metric": "sequence-space JVPs/sec (household block: BackwardIteration+ForwardIteration+aggregation, Krusell-Smith T=300)",
+            "value": total_jvps / el, "unit": "JVPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "grid": f"{n_a}x{n_e}", "T": T, "tangents_per_gpu": N,
+                       "step": "1 primal sweep + 1 batched JVP of N tangents" + (" + RCCL all-gather" if world > 1 else ""),
+                       "parallelism": f"tangent-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc,
+                         "bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_launch_s,
+                         "note": "avg launch = HIP-event time of the whole sweep / launches (includes the dependent-launch gaps)"},
+            "whole_batch": {"B_alg_bytes": b_alg_batch, "achieved_GBs": b_alg_batch / (1e-3 * ms_per_step) / 1e9,
+                            "frac_of_hbm_peak": b_alg_batch / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS},
+            "sweeps_ms": {k: round(acc[k], 4) for k in acc}, "launches": launches,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(m, ss, x, Z)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -175,43 +175,47 @@ def make_DoubleExponentialGrid(amin: float, amax: float, n_a: int) -> np.ndarray
     return amin + np.exp(np.exp(ugrid) - 1) - 1
 
 
-def invariant_dist(Π) -> np.ndarray:
-    """stationary distribution of a row-stochastic Π by the linear-system trick
-    (ForwardIteration.jl:436-442): solve (I - Πᵀ[2:,2:]) y = Πᵀ[2:,1], D = [1; y]/sum."""
+def invariant_dist(Π, D0=None, direct_max: int = 4000) -> np.ndarray:
+    """stationary distribution of a row-stochastic Π.
+
+    Chains up to `direct_max` states use the reference's linear-system trick
+    (ForwardIteration.jl:436-442): solve (I - Πᵀ[2:,2:]) y = Πᵀ[2:,1], D = [1; y]/sum. Larger chains
+    (the 2000x11 benchmark grid: a sparse LU there costs ~15 s per call) and chains where state 1 is
+    transient (the trick's normalisation D[1] = 1 is then singular — Julia's `\` would throw) use
+    the power method, warm-started from `D0` when given. Same fixed point either way."""
     import warnings
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
 
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        try:
-            if sp.issparse(Π):
-                ΠT = Π.T.tocsc()
-                n = ΠT.shape[0]
-                M = sp.identity(n - 1, format="csc") - ΠT[1:, 1:]
-                b = np.asarray(ΠT[1:, 0].todense()).ravel()
-                y = spla.spsolve(M.tocsc(), b)
-            else:
-                ΠT = np.asarray(Π, dtype=np.float64).T
-                n = ΠT.shape[0]
-                y = np.linalg.solve(np.eye(n - 1) - ΠT[1:, 1:], ΠT[1:, 0])
-        except (np.linalg.LinAlgError, RuntimeError):
-            y = np.array([np.nan])
-    D = np.concatenate([[1.0], y])
-    if np.all(np.isfinite(D)) and D.min() > -1e-12 and D.sum() > 0:
-        return D / D.sum()
-    # state 1 is transient (the trick's normalisation D[1] = 1 is then singular; Julia's `\` would
-    # throw): fall back to the power method so that the steady-state Newton can move on.
+    n = Π.shape[0]
+    if n <= direct_max:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                if sp.issparse(Π):
+                    ΠT = Π.T.tocsc()
+                    M = sp.identity(n - 1, format="csc") - ΠT[1:, 1:]
+                    b = np.asarray(ΠT[1:, 0].todense()).ravel()
+                    y = spla.spsolve(M.tocsc(), b)
+                else:
+                    ΠT = np.asarray(Π, dtype=np.float64).T
+                    y = np.linalg.solve(np.eye(n - 1) - ΠT[1:, 1:], ΠT[1:, 0])
+            except (np.linalg.LinAlgError, RuntimeError):
+                y = np.array([np.nan])
+        D = np.concatenate([[1.0], np.atleast_1d(y)])
+        if D.size == n and np.all(np.isfinite(D)) and D.min() > -1e-12 and D.sum() > 0:
+            return D / D.sum()
     A = (Π.T.tocsr() if sp.issparse(Π) else np.asarray(Π, dtype=np.float64).T)
-    D = np.full(A.shape[0], 1.0 / A.shape[0])
-    for _ in range(200_000):
+    D = np.full(n, 1.0 / n) if D0 is None else np.asarray(D0, dtype=np.float64) / np.sum(D0)
+    for k in range(500_000):
         Dn = A @ D
-        Dn /= Dn.sum()
-        if np.max(np.abs(Dn - D)) < 1e-14:
-            D = Dn
-            break
+        if k % 25 == 0:
+            Dn /= Dn.sum()
+            if np.max(np.abs(Dn - D)) < 1e-15:
+                D = Dn
+                break
         D = Dn
-    return D
+    return D / D.sum()
 
 
 def get_RouwenhorstDiscretization(n: int, ρ: float, σ: float):

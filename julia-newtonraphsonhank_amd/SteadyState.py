@@ -72,7 +72,8 @@ class SSAssembler:
                 break
             res = vf.host_steady_state_step(value, xv, model)
         Λ_endog = make_endogenous_transition(res[self.endog_dim.policy_var], self.endog_dim, self.n_exog)
-        D = invariant_dist((self.Λ_exog @ Λ_endog).T)
+        D = invariant_dist((self.Λ_exog @ Λ_endog).T, D0=getattr(self, "_D_warm", None))
+        self._D_warm = D
         for k in vars_of_type(model, "heterogeneous"):
             xv[k] = float(res[k].reshape(-1, order="F") @ D)
         return np.array([xv[k] for k in self.all_keys]), res["Value"], res
@@ -138,7 +139,7 @@ def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vf
     policies = {k: res[k] for k in het_keys}
     Λ_endog = make_endogenous_transition(policies[asm.endog_dim.policy_var], asm.endog_dim, asm.n_exog)
     Λss = (asm.Λ_exog @ Λ_endog).tocsc()
-    D = invariant_dist(Λss.T)
+    D = invariant_dist(Λss.T, D0=getattr(asm, "_D_warm", None))
     return SteadyState(vars_, policies, Λss, D, ss_value)
 
 

@@ -126,7 +126,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
     const size_t lds = primal_lds(c);
     // backward: X of the last period from the terminal value, then P fused Y;X steps, then lottery
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    (void)hipMemsetAsync(ctx->d_err, 0, 4 * sizeof(int), s);
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     hipLaunchKernelGGL(k_egm_X, grd, blk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
                        ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1);
     for (int t = P - 1; t >= 0; t--)
@@ -186,7 +186,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     if (rc) return rc;
     // forward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    (void)hipMemsetAsync(w.dD[0], 0, sizeof(double) * G * N, s);  // dD_0 = 0 (ForwardIteration.jl:293)
+    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], G * N);  // dD_0 = 0 (ForwardIteration.jl:293)
     cur = 0;
     for (int t = 0; t < (int)P; t++) {
         launch_tan_fwd(ctx, w, t, w.dD[cur], w.dD[cur ^ 1], s);
@@ -202,8 +202,8 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
 
 static int fetch_device_error(hank_ctx *ctx) {
     int e[4] = {0, 0, 0, 0};
-    HIPC(ctx, hipMemcpyAsync(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
     if (e[0] == 0) return HANK_OK;
     ctx->primal_done = false;
     switch (e[0]) {
@@ -220,7 +220,7 @@ static int fetch_device_error(hank_ctx *ctx) {
                     "savings policy is not monotone in wealth (period %d, productivity state %d, "
                     "wealth index %d)", e[1] + 1, e[2] + 1, e[3] + 1);
     default:
-        return fail(ctx, HANK_ERR_BAD_ARG, "unknown device error %d", e[0]);
+        return fail(ctx, HANK_ERR_BAD_ARG, "unknown device error %d (%d,%d,%d) d_err=%p", e[0], e[1], e[2], e[3], (void*)ctx->d_err);
     }
 }
 
@@ -496,7 +496,7 @@ static int granular_backward(hank_ctx *ctx, const double *value_next, const doub
     if (!(1.0 + xhh_t[0] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive");
     HIPC(ctx, hipMemcpyAsync(Vin, value_next, sizeof(double) * G, hipMemcpyHostToDevice, s));
     HIPC(ctx, hipMemcpyAsync(xt, xhh_t, sizeof(double) * 2, hipMemcpyHostToDevice, s));
-    HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
     hipLaunchKernelGGL(k_egm_X, grd, blk, primal_lds(c), s, c, Vin, xt, sK, kc, ctx->d_err, 0);
     hipLaunchKernelGGL(k_egm_Y, grd, blk, 0, s, c, sK, xhh_t[0], xhh_t[1], pol, ib, A, B, u, v, Vout, ctx->d_err, 0);

@@ -298,6 +298,15 @@ __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
     if (threadIdx.x == 0) aggpart[(size_t)t * gridDim.x + blockIdx.x] = tot;
 }
 
+// zero fills as kernels (no memset nodes inside the captured graphs)
+__global__ void k_zero_i32(int *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+__global__ void k_zero_f64(double *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+
 // out[t*ncol + n] = sum_b parts[(t*nb + b)*ncol + n]   (fixed order: bitwise reproducible)
 __global__ void k_reduce_parts(const double *parts, int nb, int ncol, int total, double *out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -37,7 +37,11 @@ def sharded_jvp(jvp_fn: Callable[[torch.Tensor], torch.Tensor], tangents: torch.
         out = torch.empty((N, m), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.t().contiguous(), group=group)
         return out.t()
-    parts = [torch.empty((shard_bounds(N, W, r)[1] - shard_bounds(N, W, r)[0], m), dtype=local.dtype, device=local.device)
-             for r in range(W)]
-    dist.all_gather(parts, local.t().contiguous(), group=group)
-    return torch.cat(parts, dim=0).t()
+    # ragged shards: pad every block to the widest shard, gather once, trim
+    kmax = -(-N // W)
+    padded = torch.zeros((kmax, m), dtype=local.dtype, device=local.device)
+    padded[: hi - lo] = local.t()
+    out = torch.empty((W * kmax, m), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    rows = [out[r * kmax: r * kmax + (shard_bounds(N, W, r)[1] - shard_bounds(N, W, r)[0])] for r in range(W)]
+    return torch.cat(rows, dim=0).t()

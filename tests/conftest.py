@@ -37,7 +37,15 @@ def ks_setup(n_a, n_e, T):
         from oracle.oracle import Oracle
         ov = {"T": T, "dimensions": {"wealth": {"n": n_a}, "productivity": {"n": n_e}}}
         m = h.build_model_from_yaml(str(ROOT / "examples" / "krusell_smith.yaml"), overrides=ov)
-        ss, _ = h.get_SteadyStates(m)
+        fx = ROOT / "examples" / "fixtures" / f"ks_ss_{n_a}x{n_e}.npz"
+        ss = None
+        if fx.exists() and not os.environ.get("HANK_NO_SS_FIXTURE"):
+            g = np.load(fx)
+            if np.array_equal(g["a_grid"], m.heterogeneity["wealth"].grid) and \
+                    np.array_equal(g["Pi"], m.heterogeneity["productivity"].transition):
+                ss = h.SteadyState({k: float(g[f"var_{k}"]) for k in m.variables}, {"KD": g["policy"]}, None, g["D"], g["value"])
+        if ss is None:
+            ss, _ = h.get_SteadyStates(m)
         wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
         orc = Oracle(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons)
         _SS_CACHE[key] = (m, ss, orc)

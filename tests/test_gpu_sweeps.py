@@ -1,0 +1,116 @@
+"""Sweep-level parity on the MI355X (hank_primal / hank_jvp through the C ABI) vs the CPU oracle,
+on BASELINE.json configs 1 and 2 (+ a batched variant), the committed golden vectors, and the
+Julia-exception surface. Tolerance: rel 1e-10 of the output scale + abs 1e-12."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ks_paths, ks_setup
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+
+
+def close(a, b, rel=1e-10, abs_=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    scale = max(np.max(np.abs(b)), 1e-300)
+    err = np.max(np.abs(a - b))
+    assert err <= abs_ + rel * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def run_case(hank, n_a, n_e, T, N, kind, shock, check_policies=True):
+    m, ss, orc = ks_setup(n_a, n_e, T)
+    P = T - 1
+    x, Z = ks_paths(m, ss, kind, shock)
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((4, P, N))
+    hb = hank.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    agg = hb.primal(x[2:4])
+    dagg = hb.jvp(y[2:4])
+    from oracle.oracle import pad_N, SUPPORTED_N
+    oagg_cols, opol_cols = [], []
+    for c0 in range(0, N, SUPPORTED_N[-1]):            # the oracle carries at most 32 partials per pass
+        c1 = min(N, c0 + SUPPORTED_N[-1])
+        Nc = pad_N(c1 - c0)
+        xr = np.zeros((P, 1 + Nc)); xw = np.zeros((P, 1 + Nc))
+        xr[:, 0], xw[:, 0] = x[2], x[3]
+        xr[:, 1:1 + c1 - c0], xw[:, 1:1 + c1 - c0] = y[2][:, c0:c1], y[3][:, c0:c1]
+        st, oa, op = orc.household_block(xr, xw, ss.value, ss.D, Nc)
+        assert st == 0
+        oagg0, opol0 = oa[:, 0], op[..., 0]
+        oagg_cols.append(oa[:, 1:1 + c1 - c0]); opol_cols.append(op[..., 1:1 + c1 - c0])
+    oagg = np.concatenate([oagg0[:, None]] + oagg_cols, axis=1)
+    opol = np.concatenate([opol0[..., None]] + opol_cols, axis=-1)
+    close(agg, oagg[:, 0]); close(dagg, oagg[:, 1:])
+    if check_policies:
+        close(hb.policy_seq().transpose(2, 0, 1), opol[..., 0])
+        close(hb.dpolicy_seq(N).transpose(2, 0, 1, 3), opol[..., 1:])
+        D = hb.dist_seq()
+        np.testing.assert_allclose(D.sum(axis=(0, 1)), 1.0, atol=1e-12)
+    return m, ss, orc, x, Z, y
+
+
+@pytest.mark.parametrize("kind,shock,N", [("x0", 0.0, 1), ("x1", 0.05, 1), ("x1", 0.8, 3), ("x1", 0.01, 32)])
+def test_config1_50x2_T100(hank, kind, shock, N):
+    """configs[0]: 50x2, T=100 (incl. the RunMain shock Z_t = 1 + 0.8^t, RunMain.jl:22-23)."""
+    run_case(hank, 50, 2, 100, N, kind, shock)
+
+
+@pytest.mark.parametrize("N", [1, 4])
+def test_config2_500x4_T300(hank, N):
+    """configs[1]: 500x4, T=300, single tangent (and a small batch)."""
+    run_case(hank, 500, 4, 300, N, "x1", 0.01)
+
+
+def test_odd_sizes_and_nonpow2_batch(hank):
+    """ragged shapes: n_a not a multiple of any block size, n_e = 3, N = 5 and N = 70 (> one chunk)."""
+    run_case(hank, 37, 3, 9, 5, "x1", 0.05)
+    run_case(hank, 37, 3, 9, 70, "x1", 0.05, check_policies=False)
+
+
+def test_golden_full_pipeline(hank):
+    """HIP path + host residual layer == golden F and J·y of the full KS pipeline."""
+    g = np.load(G / "ks_30x3_T25_N3.npz")
+    m, ss, orc = ks_setup(30, 3, 25)
+    assert np.array_equal(ss.value, g["ss_value"]), "steady state drifted: regenerate the golden"
+    P, N = 24, 3
+    lin = hank.LinearizedFunction(g["x"].reshape(-1, order="F"), {"Z": g["Z"]}, m, ss, ss)
+    close(lin.Fx, g["F"][..., 0].reshape(-1, order="F"))
+    Jy = lin.jvp(g["y"].reshape(4 * P, N, order="F"))
+    close(Jy, g["F"][..., 1:].reshape(4 * P, N, order="F"))
+    close(hank.household_block(m).policy_seq().transpose(2, 0, 1), g["policy_seq"][..., 0])
+
+
+def test_jvp_is_reusable_and_batch_invariant(hank):
+    """same primal, different batches: column k of a batch == the single-tangent JVP of column k,
+    and a second primal invalidates nothing silently."""
+    m, ss, orc = ks_setup(50, 2, 100)
+    P = 99
+    x, Z = ks_paths(m, ss, "x1", 0.05)
+    hb = hank.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(x[2:4])
+    y = np.random.default_rng(1).standard_normal((2, P, 6))
+    full = hb.jvp(y)
+    for k in (0, 5):
+        one = hb.jvp(y[:, :, k:k + 1])
+        close(one[:, 0], full[:, k], rel=1e-13)
+    again = hb.jvp(y)
+    assert np.array_equal(again, full)          # fixed summation order: bitwise reproducible
+
+
+def test_knots_error_from_the_sweep(hank):
+    m, ss, _ = ks_setup(50, 2, 100)
+    hb = hank.household_block(m)
+    bad = np.array(ss.value, copy=True)
+    bad[7, :] *= 1e-4
+    hb.set_boundary(bad, ss.D)
+    x, _ = ks_paths(m, ss, "x0")
+    with pytest.raises(hank.KnotsNotSortedError, match="period 99"):
+        hb.primal(x[2:4])
+    with pytest.raises(hank.HankHIPError):
+        hb.jvp(np.zeros((2, 99, 1)))          # no valid primal -> refused
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(x[2:4])                          # context recovers
