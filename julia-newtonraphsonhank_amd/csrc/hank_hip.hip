@@ -86,28 +86,6 @@ static void free_tanwork(TanWork &w) {
     w = TanWork();
 }
 
-// ---- tangent kernel dispatch over the compile-time column count ---------------------------------
-#define NE_CASES(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
-
-static void launch_tan_back(hank_ctx *ctx, TanWork &w, int t, const double *dsIn, double *dsOut, hipStream_t s) {
-    const int RB = TAN_THREADS >> w.g.lgNC;
-    dim3 grid((ctx->c.n_a + RB - 1) / RB, (w.N + w.g.NC - 1) / w.g.NC);
-    switch (ctx->c.n_e) {
-#define X(NE) case NE: hipLaunchKernelGGL(k_tan_back<NE>, grid, dim3(TAN_THREADS), 0, s, ctx->c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, t, dsIn, dsOut, w.dpol); break;
-        NE_CASES(X)
-#undef X
-    }
-}
-static void launch_tan_fwd(hank_ctx *ctx, TanWork &w, int t, const double *dDin, double *dDout, hipStream_t s) {
-    const int RB = TAN_THREADS >> w.g.lgNC;
-    dim3 grid((ctx->c.n_a + RB - 1) / RB, (w.N + w.g.NC - 1) / w.g.NC);
-    switch (ctx->c.n_e) {
-#define X(NE) case NE: hipLaunchKernelGGL(k_tan_fwd<NE>, grid, dim3(TAN_THREADS), 0, s, ctx->c, ctx->R, w.g, t, dDin, dDout, w.dpol, w.aggpart); break;
-        NE_CASES(X)
-#undef X
-    }
-}
-
 // ---- graph construction -----------------------------------------------------------------------
 static int end_capture(hank_ctx *ctx, hipGraphExec_t *out) {
     hipGraph_t graph = nullptr;
@@ -138,7 +116,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     for (int t = 0; t < P; t++)
         hipLaunchKernelGGL(k_dist_step, grd, blk, lds, s, c, ctx->R, t, ctx->d_aggpart);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((P + 255) / 256), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, P, ctx->d_agg);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
     rc = end_capture(ctx, &ctx->g_pfwd);
     ctx->launches[0] = P + 2;
     ctx->launches[1] = P + 1;
@@ -154,49 +132,52 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     w.N = N;
     int NC = 1, lg = 0;
     while (NC < N && NC < 64) { NC <<= 1; lg++; }
-    w.g.N = N; w.g.NC = NC; w.g.lgNC = lg;
-    const int RB = TAN_THREADS / NC;
+    const int RB = 64 / NC;
     w.nbx = (c.n_a + RB - 1) / RB;
+    w.g.N = N; w.g.NC = NC; w.g.lgNC = lg; w.g.nbx = w.nbx;
+    const size_t GV = (size_t)(c.n_a + KV) * c.n_e;   // dD state carries KV virtual rows per column
     HIPC(ctx, dmalloc(&w.dxhh, 2 * P * N));
     HIPC(ctx, dmalloc(&w.dxr, P * N));
     HIPC(ctx, dmalloc(&w.dxw, P * N));
     for (int k = 0; k < 2; k++) {
         HIPC(ctx, dmalloc(&w.ds[k], G * N));
-        HIPC(ctx, dmalloc(&w.dD[k], G * N));
+        HIPC(ctx, dmalloc(&w.dD[k], GV * N));
     }
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)w.nbx * N));
+    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)(w.nbx + KV) * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
 
     hipStream_t s = ctx->own_stream;
-    const int RBt = RB;
-    const dim3 grid((c.n_a + RBt - 1) / RBt, (N + NC - 1) / NC);
+    const dim3 blk(64 * c.n_e);
+    const unsigned ny = (N + NC - 1) / NC;
     const int PN = (int)(P * N);
     // backward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    hipLaunchKernelGGL(k_tan_back_init, grid, dim3(TAN_THREADS), 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, (int)P - 1, w.ds[0]);
+    hipLaunchKernelGGL(k_tan_back, dim3(w.nbx, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, (int)P - 1, 1,
+                       w.ds[1], w.ds[0], w.dpol);
     int cur = 0;
     for (int t = (int)P - 1; t >= 0; t--) {
-        launch_tan_back(ctx, w, t, w.ds[cur], w.ds[cur ^ 1], s);
+        hipLaunchKernelGGL(k_tan_back, dim3(w.nbx, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, t, 0,
+                           w.ds[cur], w.ds[cur ^ 1], w.dpol);
         cur ^= 1;
     }
     int rc = end_capture(ctx, &w.g_back);
     if (rc) return rc;
     // forward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], G * N);  // dD_0 = 0 (ForwardIteration.jl:293)
+    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
     cur = 0;
     for (int t = 0; t < (int)P; t++) {
-        launch_tan_fwd(ctx, w, t, w.dD[cur], w.dD[cur ^ 1], s);
+        hipLaunchKernelGGL(k_tan_fwd, dim3(w.nbx + KV, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
         cur ^= 1;
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((PN + 255) / 256), dim3(256), 0, s, w.aggpart, w.nbx, N, PN, w.dagg);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, w.nbx + KV, N, w.dagg);
     hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
     rc = end_capture(ctx, &w.g_fwd);
     ctx->launches[2] = (int)P + 2;
-    ctx->launches[3] = (int)P + 2;
+    ctx->launches[3] = (int)P + 3;
     return rc;
 }
 
@@ -274,6 +255,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, dmalloc(&R.ig, P * G)); HIPC(ctx, dmalloc(&R.Dseq, (P + 1) * G));
     HIPC(ctx, dmalloc(&R.ib, P * G)); HIPC(ctx, dmalloc(&R.lo, P * G));
     HIPC(ctx, dmalloc(&R.start, P * (size_t)c.n_e * (c.n_a + 1)));
+    HIPC(ctx, dmalloc(&R.clo, P * (size_t)c.n_e));
     HIPC(ctx, dmalloc(&ctx->d_ss_value, G));
     ctx->d_ss_D = R.Dseq;
     ctx->nbp = (c.n_a + RBP - 1) / RBP;
@@ -296,7 +278,7 @@ int hank_destroy(hank_ctx *ctx) {
     if (ctx->g_pfwd) (void)hipGraphExecDestroy(ctx->g_pfwd);
     Record &R = ctx->R;
     (void)hipFree(R.s); (void)hipFree(R.kc); (void)hipFree(R.A); (void)hipFree(R.B); (void)hipFree(R.u); (void)hipFree(R.v);
-    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start);
+    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
     (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 8; k++)

@@ -20,8 +20,6 @@
 namespace hank {
 
 constexpr int RBP = 32;        // rows (wealth points) per block in the primal kernels
-constexpr int TAN_THREADS = 256;
-constexpr int HEAVY = 48;      // lottery segments longer than this are summed by the whole block
 
 struct Consts {
     int n_a, n_e, G, P;
@@ -31,7 +29,7 @@ struct Consts {
 
 struct Record {
     double *s, *kc, *A, *B, *u, *v, *pol, *lw, *ig, *Dseq;
-    int *ib, *lo, *start;
+    int *ib, *lo, *start, *clo;
 };
 
 enum { ERR_KNOTS = 3, ERR_DOMAIN = 4, ERR_NONMONO = 6 };
@@ -195,15 +193,23 @@ __global__ void k_egm_step(Consts c, Record R, const double *xhh, int t, int *er
 }
 
 // ---- Young lottery for every (period, column) at once (ForwardIteration.jl:37-78) ------------
-// one block per column; builds lo / lw / ig and the segment offsets `start` that turn the
-// 2-nnz-per-column scatter into a deterministic gather (the policy is monotone in wealth).
+// one block per column; builds lo / lw / ig and the segment offsets that turn the 2-nnz-per-column
+// scatter into a deterministic gather (the policy is monotone in wealth):
+//   clo      = number of sources clamped at the FIRST grid point (policy <= grid[1], :54-58): a
+//              prefix [0, clo) of the column, all mass to row 0 with weight one and no weight
+//              tangent — the borrowing-constraint mass point, summed separately (it is long);
+//   start[r] = max(clo, first source j with lo_j >= r): target row r receives w_j from the sources
+//              in [start[r-1], start[r]) and 1-w_j from those in [start[r], start[r+1]).
 __global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
     extern __shared__ int shlo[];
+    __shared__ int sh_clo;
     const int col = blockIdx.x;
     if (col >= ncols) return;
     const int t = col / c.n_e, e = col % c.n_e;
     const size_t base = (size_t)col * c.n_a;  // == t*G + e*n_a
     const int n = c.n_a;
+    if (threadIdx.x == 0) sh_clo = 0;
+    __syncthreads();
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const double p = R.pol[base + j];
         int lo = -1, hi = n;  // grid[lo] < p <= grid[hi]  (searchsortedfirst, :52)
@@ -215,6 +221,7 @@ __global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
         double w, ig;
         if (hi == 0) {            // m == 1: all mass on the first point (:54-58)
             l = 0; w = 0.0; ig = 0.0;
+            atomicMax(&sh_clo, j + 1);
         } else if (hi >= n) {     // m > n_a: all mass on the last point (:59-63)
             l = n - 2; w = 1.0; ig = 0.0;
         } else {                  // interior (:64-73)
@@ -224,65 +231,48 @@ __global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
             ig = 1.0 / gap;
         }
         R.lo[base + j] = l; R.lw[base + j] = w; R.ig[base + j] = ig;
-        shlo[j] = l;
+        shlo[j] = (hi == 0) ? -1 : l;   // clamped-low sources sort before every interior bracket
     }
     __syncthreads();
+    const int clo = sh_clo;
+    if (threadIdx.x == 0) R.clo[col] = clo;
     int *st = R.start + (size_t)col * (n + 1);
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const int prev = j ? shlo[j - 1] : -1, cur = shlo[j];
         if (cur < prev) set_err(err, ERR_NONMONO, t, e, j);
-        for (int r = prev + 1; r <= cur; r++) st[r] = j;
+        for (int r = (prev < 0 ? 0 : prev + 1); r <= cur; r++) st[r] = j;   // j >= clo whenever cur >= 0
         if (j == n - 1)
-            for (int r = cur + 1; r <= n; r++) st[r] = n;
+            for (int r = (cur < 0 ? 0 : cur + 1); r <= n; r++) st[r] = n;
     }
 }
 
 // ---- distribution push-forward, one period (ForwardIteration.jl:95-99, :297-308) -------------
-// block = RBP rows x n_e; dynamic LDS: Dsh[n_e*RBP] + Pish[n_e*n_e] + red[16] + heavy list
+// block = RBP rows x n_e, thread (row, e) with row fastest (a 32-lane half-wave per column);
+// dynamic LDS: Dsh[n_e*RBP] + Pish[n_e*n_e] + red[16]
 __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
     extern __shared__ double sh[];
     double *Dsh = sh, *Pish = sh + c.n_e * RBP, *red = Pish + c.n_e * c.n_e;
-    __shared__ int nheavy;
-    __shared__ int heavy[64];
     const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
     const int r = blockIdx.x * RBP + row;
     const int n = c.n_a;
-    if (threadIdx.x == 0) nheavy = 0;
     for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
-    __syncthreads();
     const double *Dprev = R.Dseq + (size_t)t * c.G;
     const size_t base = (size_t)t * c.G;
+    const double *lw = R.lw + base + (size_t)e * n, *Dp = Dprev + (size_t)e * n;
     double acc = 0.0;
     if (r < n) {
         const int *st = R.start + ((size_t)t * c.n_e + e) * (n + 1);
         const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
-        bool mine = true;
-        if (st2 - st0 > HEAVY) {
-            const int slot = atomicAdd(&nheavy, 1);
-            if (slot < 64) { heavy[slot] = threadIdx.x; mine = false; }
-        }
-        if (mine) {
-            const double *lw = R.lw + base + (size_t)e * n, *Dp = Dprev + (size_t)e * n;
-            for (int j = st0; j < st1; j++) acc += lw[j] * Dp[j];
-            for (int j = st1; j < st2; j++) acc += (1.0 - lw[j]) * Dp[j];
-        }
+        for (int j = st0; j < st1; j++) acc += lw[j] * Dp[j];
+        for (int j = st1; j < st2; j++) acc += (1.0 - lw[j]) * Dp[j];
     }
-    __syncthreads();
-    const int nh = nheavy < 64 ? nheavy : 64;
-    for (int h = 0; h < nh; h++) {  // long segments (the borrowing-constraint mass point)
-        const int owner = heavy[h];
-        const int hrow = owner % RBP, he = owner / RBP, hr = blockIdx.x * RBP + hrow;
-        const int *st = R.start + ((size_t)t * c.n_e + he) * (n + 1);
-        const int st1 = st[hr], st2 = st[hr + 1], st0 = hr > 0 ? st[hr - 1] : st1;
-        const double *lw = R.lw + base + (size_t)he * n, *Dp = Dprev + (size_t)he * n;
+    if (blockIdx.x == 0) {  // the mass point: sum_{j < clo} D_prev[j] -> row 0, by the column's 32 lanes
+        const int clo = R.clo[(size_t)t * c.n_e + e];
         double part = 0.0;
-        for (int j = st0 + threadIdx.x; j < st2; j += blockDim.x)
-            part += (j < st1 ? lw[j] : (1.0 - lw[j])) * Dp[j];
-        const double tot = block_sum(part, red);
-        if (threadIdx.x == 0) Dsh[he * RBP + hrow] = tot;
-        __syncthreads();
-        if (threadIdx.x == owner) acc = Dsh[he * RBP + hrow];
-        __syncthreads();
+        for (int j = row; j < clo; j += RBP) part += Dp[j];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (row == 0) acc += part;
     }
     if (r < n) Dsh[e * RBP + row] = acc;
     __syncthreads();
@@ -307,24 +297,34 @@ __global__ void k_zero_f64(double *p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0;
 }
 
-// out[t*ncol + n] = sum_b parts[(t*nb + b)*ncol + n]   (fixed order: bitwise reproducible)
-__global__ void k_reduce_parts(const double *parts, int nb, int ncol, int total, double *out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int t = idx / ncol, n = idx - t * ncol;
-    const double *p = parts + (size_t)t * nb * ncol + n;
+// out[t*N + n] = sum_b parts[(t*nb + b)*N + n]; one block per (t, 64-wide tangent chunk), four
+// groups of 64 lanes stride over the row blocks, fixed combination order: bitwise reproducible
+__global__ void k_reduce_parts(const double *parts, int nb, int N, double *out) {
+    __shared__ double red[256];
+    const int t = blockIdx.x, nl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n = blockIdx.y * 64 + nl;
     double s = 0.0;
-    for (int b = 0; b < nb; b++) s += p[(size_t)b * ncol];
-    out[idx] = s;
+    if (n < N) {
+        const double *p = parts + (size_t)t * nb * N + n;
+        for (int b = g; b < nb; b += 4) s += p[(size_t)b * N];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && n < N) out[(size_t)t * N + n] = (red[nl] + red[64 + nl]) + (red[128 + nl] + red[192 + nl]);
 }
 
 // ---- tangent sweeps ------------------------------------------------------------------------
-// thread <-> (wealth row a, tangent n); loops over the NE productivity columns so the n_e x n_e
-// mixing is register-local. NC = tangents per block row (power of two), RB = 256/NC rows.
-struct TanGeom { int N, NC, lgNC; };
+// One wavefront per productivity column e: lane = (tangent nl fastest, wealth row rl), so a wave
+// instruction moves RB = 64/NC adjacent rows x NC tangents = one contiguous 512-byte piece of the
+// [e][a][N] state. The n_e x n_e mixing goes through a 64 x n_e LDS tile (conflict-free: the lane
+// is the fastest LDS index). Block = 64*n_e threads.
+// KV virtual rows per column (rows n_a .. n_a+KV-1 of the dD state) hold partial sums of the
+// mass-point row 0 — see k_tan_fwd.
+constexpr int KV = 16;
+struct TanGeom { int N, NC, lgNC, nbx; };   // nbx = regular row blocks = ceil(n_a / (64/NC))
 
 // (n_hh, P, N) column-major  ->  dxr[P][N], dxw[P][N]
-__global__ void k_tan_in(const double *dxhh, int P, int N, double *dxr, double *dxw) {
+__global__ void k_tan_in(const double *__restrict__ dxhh, int P, int N, double *__restrict__ dxr, double *__restrict__ dxw) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P * N) return;
     const int t = idx / N, n = idx - t * N;
@@ -332,114 +332,139 @@ __global__ void k_tan_in(const double *dxhh, int P, int N, double *dxr, double *
     dxw[idx] = dxhh[1 + 2 * ((size_t)t + (size_t)P * n)];
 }
 // dagg[P][N] -> (P, N) column-major
-__global__ void k_tan_out(const double *dagg, int P, int N, double *out) {
+__global__ void k_tan_out(const double *__restrict__ dagg, int P, int N, double *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P * N) return;
     const int n = idx / P, t = idx - n * P;
     out[idx] = dagg[(size_t)t * N + n];
 }
 
-// knot tangents of the last period: dV_T = 0 (terminal value has zero partials,
-// BackwardIteration.jl:85) => ds = -rho*(z_e*dw + s*dr)
-__global__ void k_tan_back_init(Consts c, Record R, const double *xhh, const double *dxr,
-                                const double *dxw, TanGeom g, int t, double *dsOut) {
-    const int nl = threadIdx.x & (g.NC - 1), rl = threadIdx.x >> g.lgNC;
-    const int a = blockIdx.x * (TAN_THREADS >> g.lgNC) + rl, n = blockIdx.y * g.NC + nl;
-    if (a >= c.n_a || n >= g.N) return;
-    const double rho = 1.0 / (1.0 + xhh[2 * t]);
-    const double dr = dxr[(size_t)t * g.N + n], dw = dxw[(size_t)t * g.N + n];
-    for (int e = 0; e < c.n_e; e++) {
-        const size_t off = (size_t)t * c.G + (size_t)e * c.n_a + a;
-        dsOut[((size_t)e * c.n_a + a) * g.N + n] = -rho * (c.z[e] * dw + R.s[off] * dr);
-    }
-}
-
 // one backward period: Y-tangent of period t (bracket gather -> dpol_t, dV_t), then X-tangent of
-// period t-1 (mix over e -> knot tangents). dsIn/dsOut ping-pong in L2 / Infinity Cache.
-template <int NE>
-__global__ void __launch_bounds__(TAN_THREADS)
-k_tan_back(Consts c, Record R, const double *xhh, const double *dxr, const double *dxw, TanGeom g,
-           int t, const double *dsIn, double *dsOut, double *dpol) {
-    const int nl = threadIdx.x & (g.NC - 1), rl = threadIdx.x >> g.lgNC;
-    const int a = blockIdx.x * (TAN_THREADS >> g.lgNC) + rl, n = blockIdx.y * g.NC + nl;
-    if (a >= c.n_a || n >= g.N) return;
+// period t-1 (mix over e -> knot tangents ds_{t-1}). `first`: dV_{t+1} = 0 for the last period
+// (terminal value has zero partials, BackwardIteration.jl:85) => only the X half, from zeros.
+// ds ping-pongs between two [e][a][N] buffers that live in L2 / Infinity Cache.
+__global__ void __launch_bounds__(1024)
+k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__restrict__ dxr,
+           const double *__restrict__ dxw, TanGeom g, int t, int first, const double *__restrict__ dsIn,
+           double *__restrict__ dsOut, double *__restrict__ dpol) {
+    __shared__ double dVsh[16 * 64];
+    __shared__ double Pish[256];
+    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
+    const int a = blockIdx.x * (64 >> g.lgNC) + rl, n = blockIdx.y * g.NC + nl;
+    const bool valid = (a < c.n_a) && (n < g.N);
     const size_t N = g.N;
-    const double dr = dxr[(size_t)t * N + n], dw = dxw[(size_t)t * N + n];
-    const double xa = c.a[a];
-    double dV[NE];
-    const size_t base = (size_t)t * c.G;
-#pragma unroll
-    for (int e = 0; e < NE; e++) {
-        const size_t off = base + (size_t)e * c.n_a + a;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    const size_t pt = (size_t)e * c.n_a + a;
+    double dV = 0.0;
+    if (valid && !first) {
+        const size_t off = (size_t)t * c.G + pt;
         const int i = R.ib[off];
-        const double A = R.A[off], B = R.B[off];
         const double *col = dsIn + ((size_t)e * c.n_a) * N + n;
-        const double dg = A * col[(size_t)i * N] + B * col[(size_t)(i + 1) * N];
+        const double ds0 = col[(size_t)i * N], ds1 = col[(size_t)(i + 1) * N];
+        const double dr = dxr[(size_t)t * N + n], dw = dxw[(size_t)t * N + n];
+        const double dg = R.A[off] * ds0 + R.B[off] * ds1;
         dpol[off * N + n] = dg;
-        dV[e] = R.u[off] * dr + R.v[off] * ((xa * dr + c.z[e] * dw) - dg);
+        dV = R.u[off] * dr + R.v[off] * ((c.a[a] * dr + c.z[e] * dw) - dg);
     }
-    if (t == 0) return;
-    const double rho1 = 1.0 / (1.0 + xhh[2 * (t - 1)]);
-    const double dr1 = dxr[(size_t)(t - 1) * N + n], dw1 = dxw[(size_t)(t - 1) * N + n];
-#pragma unroll
-    for (int e = 0; e < NE; e++) {
-        double dE = dV[0] * c.Pi[e];
-#pragma unroll
-        for (int e2 = 1; e2 < NE; e2++) dE += dV[e2] * c.Pi[e + NE * e2];
-        const size_t off1 = base - c.G + (size_t)e * c.n_a + a;
-        dsOut[((size_t)e * c.n_a + a) * N + n] = R.kc[off1] * dE - rho1 * (c.z[e] * dw1 + R.s[off1] * dr1);
+    dVsh[e * 64 + lane] = dV;
+    __syncthreads();
+    const int tx = first ? t : t - 1;   // period whose knots are produced
+    if (valid && tx >= 0) {
+        double dE = dVsh[lane] * Pish[e];
+        for (int e2 = 1; e2 < c.n_e; e2++) dE += dVsh[e2 * 64 + lane] * Pish[e + c.n_e * e2];
+        const size_t off1 = (size_t)tx * c.G + pt;
+        const double rho1 = 1.0 / (1.0 + xhh[2 * tx]);
+        const double dr1 = dxr[(size_t)tx * N + n], dw1 = dxw[(size_t)tx * N + n];
+        dsOut[pt * N + n] = R.kc[off1] * dE - rho1 * (c.z[e] * dw1 + R.s[off1] * dr1);
     }
 }
 
-// one forward period: segment gather of the lottery tangent, mix over e, aggregate.
-// dagg_t = sum( dpol_t * D_t + pol_t * dD_t ) with the POST-transition D_t.
-template <int NE>
-__global__ void __launch_bounds__(TAN_THREADS)
-k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *dDin, double *dDout,
-          const double *dpol, double *aggpart) {
-    __shared__ double red[TAN_THREADS];
-    const int nl = threadIdx.x & (g.NC - 1), rl = threadIdx.x >> g.lgNC;
-    const int RB = TAN_THREADS >> g.lgNC;
-    const int r = blockIdx.x * RB + rl, n = blockIdx.y * g.NC + nl;
+// one forward period: segment gather of the lottery tangent (ForwardIteration.jl:37-99 under
+// Dual), mix over e, aggregate dagg_t = sum(dpol_t * D_t + pol_t * dD_t) with the POST-transition
+// D_t (:301-307). dD state: [e][n_a + KV][N].
+//   blocks [0, nbx):      regular target rows; sources j >= clo only.
+//   blocks [nbx, nbx+KV): the mass point. Block p sums its share of the clamped prefix [0, clo_e)
+//     of every column (weight one, no weight tangent) plus, when row 0 itself is clamped, its share
+//     of last period's virtual rows; after the mix the result is stored as VIRTUAL ROW n_a+p: row
+//     0's tangent is (real row 0) + sum_p (virtual row p). Everything downstream is linear, so the
+//     parts are never combined: a virtual row is a source with row 0's lottery (no own policy
+//     tangent), and its aggregate term uses pol[0, e].
+__global__ void __launch_bounds__(1024)
+k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin, double *__restrict__ dDout,
+          const double *__restrict__ dpol, double *__restrict__ aggpart) {
+    __shared__ double sh[16 * 64];
+    __shared__ double Pish[256];
+    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
+    const int RB = 64 >> g.lgNC;
+    const int n = blockIdx.y * g.NC + nl;
     const size_t N = g.N;
-    const int na = c.n_a;
-    double part = 0.0;
-    if (r < na && n < g.N) {
-        const size_t base = (size_t)t * c.G;
-        const double *Dprev = R.Dseq + base, *Dnew = R.Dseq + base + c.G;
-        double acc[NE];
-#pragma unroll
-        for (int e = 0; e < NE; e++) {
-            const int *st = R.start + ((size_t)t * NE + e) * (na + 1);
+    const int na = c.n_a, nav = c.n_a + KV;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    const size_t base = (size_t)t * c.G, cb = base + (size_t)e * na;
+    const double *Dprev = R.Dseq + base + (size_t)e * na, *Dnew = R.Dseq + base + c.G;
+    const double *dDc = dDin + ((size_t)e * nav) * N + n;
+    const double *dpc = dpol + cb * N + n;
+    const int *st = R.start + ((size_t)t * c.n_e + e) * (na + 1);
+    const int clo = R.clo[(size_t)t * c.n_e + e];
+    const bool virt_block = (int)blockIdx.x >= g.nbx;
+    const bool nok = n < g.N;
+    int r;          // row of the dD state this thread produces
+    bool valid;
+    double acc = 0.0;
+    if (!virt_block) {
+        r = blockIdx.x * RB + rl;
+        valid = (r < na) && nok;
+        if (valid) {
             const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
-            const size_t cb = base + (size_t)e * na;
-            const double *dDc = dDin + ((size_t)e * na) * N + n;
-            const double *dpc = dpol + cb * N + n;
-            double s = 0.0;
             for (int j = st0; j < st1; j++)
-                s += R.lw[cb + j] * dDc[(size_t)j * N] + (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[(size_t)e * na + j];
+                acc += R.lw[cb + j] * dDc[(size_t)j * N] + (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
             for (int j = st1; j < st2; j++)
-                s += (1.0 - R.lw[cb + j]) * dDc[(size_t)j * N] - (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[(size_t)e * na + j];
-            acc[e] = s;
+                acc += (1.0 - R.lw[cb + j]) * dDc[(size_t)j * N] - (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
+            // row 0 not clamped: its virtual rows follow row 0's (interior) lottery
+            if (clo == 0 && st2 > 0 && (st0 == 0 || st1 == 0)) {
+                const double w0 = (st0 == 0 && st1 > 0) ? R.lw[cb] : 1.0 - R.lw[cb];
+                double v = 0.0;
+                for (int k = 0; k < KV; k++) v += dDc[(size_t)(na + k) * N];
+                acc += w0 * v;
+            }
         }
-#pragma unroll
-        for (int e2 = 0; e2 < NE; e2++) {
-            double dDn = acc[0] * c.Pi[NE * e2];
-#pragma unroll
-            for (int e = 1; e < NE; e++) dDn += acc[e] * c.Pi[e + NE * e2];
+    } else {
+        const int p = blockIdx.x - g.nbx;
+        r = na + p;
+        valid = nok && (rl == 0);
+        if (nok && clo > 0) {
+            const int M = clo + KV;                         // clamped sources, then the virtual rows
+            const int lo = (int)(((long long)M * p) / KV), hi = (int)(((long long)M * (p + 1)) / KV);
+            for (int i = lo + rl; i < hi; i += RB)
+                acc += dDc[(size_t)(i < clo ? i : na + (i - clo)) * N];
+        }
+        for (int off = 32; off >= g.NC; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    }
+    sh[e * 64 + lane] = acc;
+    __syncthreads();
+    double part = 0.0;
+    if (valid) {
+        const int e2 = e;
+        double dDn = sh[lane] * Pish[c.n_e * e2];
+        for (int k = 1; k < c.n_e; k++) dDn += sh[k * 64 + lane] * Pish[k + c.n_e * e2];
+        dDout[((size_t)e2 * nav + r) * N + n] = dDn;
+        if (!virt_block) {
             const size_t off = base + (size_t)e2 * na + r;
-            dDout[((size_t)e2 * na + r) * N + n] = dDn;
-            part += R.pol[off] * dDn + dpol[off * N + n] * Dnew[(size_t)e2 * na + r];
+            part = R.pol[off] * dDn + dpol[off * N + n] * Dnew[(size_t)e2 * na + r];
+        } else {
+            part = R.pol[base + (size_t)e2 * na] * dDn;
         }
     }
-    // sum over the RB rows of this block for each tangent lane
-    red[threadIdx.x] = part;
     __syncthreads();
-    if (threadIdx.x < g.NC) {
-        double s = 0.0;
-        for (int k = 0; k < RB; k++) s += red[k * g.NC + threadIdx.x];
-        const int nn = blockIdx.y * g.NC + threadIdx.x;
-        if (nn < g.N) aggpart[((size_t)t * gridDim.x + blockIdx.x) * N + nn] = s;
+    sh[e * 64 + lane] = part;
+    __syncthreads();
+    if (e == 0) {   // sum over columns, then over the RB row lanes of each tangent
+        double s = sh[lane];
+        for (int k = 1; k < c.n_e; k++) s += sh[k * 64 + lane];
+        for (int off = 32; off >= g.NC; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (rl == 0 && nok) aggpart[((size_t)t * gridDim.x + blockIdx.x) * N + n] = s;
     }
 }
 
