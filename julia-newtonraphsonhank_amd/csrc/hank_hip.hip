@@ -38,7 +38,7 @@ struct hank_ctx {
     int T = 0;
     double *d_a = nullptr, *d_z = nullptr, *d_Pi = nullptr;
     double *d_ss_value = nullptr, *d_ss_D = nullptr;  // d_ss_D aliases Dseq[0]
-    double *d_xhh = nullptr, *d_agg = nullptr, *d_aggpart = nullptr;
+    double *d_xhh = nullptr, *d_agg = nullptr, *d_aggpart = nullptr, *d_rho = nullptr;
     int *d_err = nullptr;
     int nbp = 0;  // row blocks of the primal kernels
     bool boundary_set = false, primal_done = false;
@@ -86,6 +86,31 @@ static void free_tanwork(TanWork &w) {
     w = TanWork();
 }
 
+// ---- tangent kernel dispatch over the compile-time tangents-per-wave-row --------------------------
+#define LG_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+
+static void launch_tan_back(hank_ctx *ctx, TanWork &w, int t, int first, const double *dsIn, double *dsOut, hipStream_t s) {
+    const Consts &c = ctx->c;
+    const dim3 grid(w.nbx, (w.N + w.g.NC - 1) / w.g.NC), blk(64 * c.n_e);
+    switch (w.g.lgNC) {
+#define X(L) case L: hipLaunchKernelGGL(k_tan_back<L>, grid, blk, 0, s, c.n_a, c.n_e, c.G, w.N, t, first, c.a, c.z, c.Pi, \
+                                        TAN_REC_ARGS(ctx->R, ctx->d_rho), w.dxr, w.dxw, dsIn, dsOut, w.dpol); break;
+        LG_CASES(X)
+#undef X
+    }
+}
+static void launch_tan_fwd(hank_ctx *ctx, TanWork &w, int t, const double *dDin, double *dDout, hipStream_t s) {
+    const Consts &c = ctx->c;
+    const Record &R = ctx->R;
+    const dim3 grid(w.nbx + KV, (w.N + w.g.NC - 1) / w.g.NC), blk(64 * c.n_e);
+    switch (w.g.lgNC) {
+#define X(L) case L: hipLaunchKernelGGL(k_tan_fwd<L>, grid, blk, 0, s, c.n_a, c.n_e, c.G, w.N, w.nbx, t, c.Pi, R.lw, R.ig, R.Dseq, \
+                                        R.pol, R.start, R.clo, dDin, dDout, w.dpol, w.aggpart); break;
+        LG_CASES(X)
+#undef X
+    }
+}
+
 // ---- graph construction -----------------------------------------------------------------------
 static int end_capture(hank_ctx *ctx, hipGraphExec_t *out) {
     hipGraph_t graph = nullptr;
@@ -105,6 +130,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
     // backward: X of the last period from the terminal value, then P fused Y;X steps, then lottery
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
+    hipLaunchKernelGGL(k_rho, dim3((P + 255) / 256), dim3(256), 0, s, ctx->d_xhh, P, ctx->d_rho);
     hipLaunchKernelGGL(k_egm_X, grd, blk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
                        ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1);
     for (int t = P - 1; t >= 0; t--)
@@ -118,7 +144,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
         hipLaunchKernelGGL(k_dist_step, grd, blk, lds, s, c, ctx->R, t, ctx->d_aggpart);
     hipLaunchKernelGGL(k_reduce_parts, dim3(P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
     rc = end_capture(ctx, &ctx->g_pfwd);
-    ctx->launches[0] = P + 2;
+    ctx->launches[0] = P + 4;
     ctx->launches[1] = P + 1;
     return rc;
 }
@@ -149,18 +175,14 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
 
     hipStream_t s = ctx->own_stream;
-    const dim3 blk(64 * c.n_e);
-    const unsigned ny = (N + NC - 1) / NC;
     const int PN = (int)(P * N);
     // backward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    hipLaunchKernelGGL(k_tan_back, dim3(w.nbx, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, (int)P - 1, 1,
-                       w.ds[1], w.ds[0], w.dpol);
+    launch_tan_back(ctx, w, (int)P - 1, 1, w.ds[1], w.ds[0], s);
     int cur = 0;
     for (int t = (int)P - 1; t >= 0; t--) {
-        hipLaunchKernelGGL(k_tan_back, dim3(w.nbx, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, t, 0,
-                           w.ds[cur], w.ds[cur ^ 1], w.dpol);
+        launch_tan_back(ctx, w, t, 0, w.ds[cur], w.ds[cur ^ 1], s);
         cur ^= 1;
     }
     int rc = end_capture(ctx, &w.g_back);
@@ -170,7 +192,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
     cur = 0;
     for (int t = 0; t < (int)P; t++) {
-        hipLaunchKernelGGL(k_tan_fwd, dim3(w.nbx + KV, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+        launch_tan_fwd(ctx, w, t, w.dD[cur], w.dD[cur ^ 1], s);
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, w.nbx + KV, N, w.dagg);
@@ -261,6 +283,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     ctx->nbp = (c.n_a + RBP - 1) / RBP;
     HIPC(ctx, dmalloc(&ctx->d_xhh, 2 * P));
     HIPC(ctx, dmalloc(&ctx->d_agg, P));
+    HIPC(ctx, dmalloc(&ctx->d_rho, P));
     HIPC(ctx, dmalloc(&ctx->d_aggpart, P * (size_t)ctx->nbp));
     HIPC(ctx, dmalloc(&ctx->d_err, 4));
     HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
@@ -280,7 +303,7 @@ int hank_destroy(hank_ctx *ctx) {
     (void)hipFree(R.s); (void)hipFree(R.kc); (void)hipFree(R.A); (void)hipFree(R.B); (void)hipFree(R.u); (void)hipFree(R.v);
     (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
-    (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
+    (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_rho); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 8; k++)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
