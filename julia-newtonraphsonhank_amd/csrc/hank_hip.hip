@@ -4,6 +4,7 @@
 // Y half of period t, so the loop-carried state only crosses a launch boundary once per period,
 // and the 2(T-1) dependent launches are replayed from hipGraphs (no host launch cost).
 #include "hank_kernels.h"
+#include "hank_cluster.h"
 #include "../../include/hank_hip.h"
 
 #include <cstdarg>
@@ -17,16 +18,18 @@ using namespace hank;
 
 struct TanWork {
     int N = 0;
-    TanGeom g{};
+    ClGeom g{};
+    int npass = 0;
+    size_t lds_back = 0, lds_fwd = 0;
     double *dxhh = nullptr;   // (2,P,N) staging for the host-pointer entry
     double *dxr = nullptr, *dxw = nullptr;
-    double *ds[2] = {nullptr, nullptr};
-    double *dD[2] = {nullptr, nullptr};
-    double *dpol = nullptr;
-    double *aggpart = nullptr;
+    double *xbuf = nullptr;     // [nclusters][2][G] exchange tiles (L2-resident)
+    unsigned *flags = nullptr;  // [2][nclusters*CS] epoch flags (backward, forward) + timeout word
+    double *dpol = nullptr;     // [N][P][G]
+    double *aggpart = nullptr;  // [N][P][CS]
     double *dagg = nullptr;     // [P][N]
     double *dagg_cm = nullptr;  // (P,N) column-major
-    int nbx = 0;
+    int nflags = 0;
     hipGraphExec_t g_back = nullptr, g_fwd = nullptr;
     bool valid = false;  // dpol holds the partials of the current primal
 };
@@ -41,6 +44,7 @@ struct hank_ctx {
     double *d_xhh = nullptr, *d_agg = nullptr, *d_aggpart = nullptr, *d_rho = nullptr;
     int *d_err = nullptr;
     int nbp = 0;  // row blocks of the primal kernels
+    int n_cu = 0;
     bool boundary_set = false, primal_done = false;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipGraphExec_t g_pback = nullptr, g_pfwd = nullptr;
@@ -80,35 +84,40 @@ static size_t primal_lds(const Consts &c) { return sizeof(double) * ((size_t)c.n
 static void free_tanwork(TanWork &w) {
     if (w.g_back) (void)hipGraphExecDestroy(w.g_back);
     if (w.g_fwd) (void)hipGraphExecDestroy(w.g_fwd);
-    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw);
-    (void)hipFree(w.ds[0]); (void)hipFree(w.ds[1]); (void)hipFree(w.dD[0]); (void)hipFree(w.dD[1]);
+    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw); (void)hipFree(w.xbuf); (void)hipFree(w.flags);
     (void)hipFree(w.dpol); (void)hipFree(w.aggpart); (void)hipFree(w.dagg); (void)hipFree(w.dagg_cm);
     w = TanWork();
 }
 
-// ---- tangent kernel dispatch over the compile-time tangents-per-wave-row --------------------------
-#define LG_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6)
+// ---- cluster sweep launches (dispatch over the compile-time passes per slab) ----------------------
+#define NPASS_CASES(X) X(1) X(2) X(4) X(8)
 
-static void launch_tan_back(hank_ctx *ctx, TanWork &w, int t, int first, const double *dsIn, double *dsOut, hipStream_t s) {
+static hipError_t launch_tanc_back(hank_ctx *ctx, TanWork &w, hipStream_t s) {
     const Consts &c = ctx->c;
-    const dim3 grid(w.nbx, (w.N + w.g.NC - 1) / w.g.NC), blk(64 * c.n_e);
-    switch (w.g.lgNC) {
-#define X(L) case L: hipLaunchKernelGGL(k_tan_back<L>, grid, blk, 0, s, c.n_a, c.n_e, c.G, w.N, t, first, c.a, c.z, c.Pi, \
-                                        TAN_REC_ARGS(ctx->R, ctx->d_rho), w.dxr, w.dxw, dsIn, dsOut, w.dpol); break;
-        LG_CASES(X)
+    const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * c.n_e);
+    switch (w.npass) {
+#define X(NP) case NP: \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_back<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_back); \
+        hipLaunchKernelGGL(k_tanc_back<NP>, grid, blk, w.lds_back, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.a, c.z, c.Pi, \
+                           TAN_REC_ARGS(ctx->R, ctx->d_rho), w.dxr, w.dxw, w.xbuf, w.flags, w.flags + 2 * w.nflags, w.dpol); break;
+        NPASS_CASES(X)
 #undef X
     }
+    return hipGetLastError();
 }
-static void launch_tan_fwd(hank_ctx *ctx, TanWork &w, int t, const double *dDin, double *dDout, hipStream_t s) {
+static hipError_t launch_tanc_fwd(hank_ctx *ctx, TanWork &w, hipStream_t s) {
     const Consts &c = ctx->c;
     const Record &R = ctx->R;
-    const dim3 grid(w.nbx + KV, (w.N + w.g.NC - 1) / w.g.NC), blk(64 * c.n_e);
-    switch (w.g.lgNC) {
-#define X(L) case L: hipLaunchKernelGGL(k_tan_fwd<L>, grid, blk, 0, s, c.n_a, c.n_e, c.G, w.N, w.nbx, t, c.Pi, R.lw, R.ig, R.Dseq, \
-                                        R.pol, R.start, R.clo, dDin, dDout, w.dpol, w.aggpart); break;
-        LG_CASES(X)
+    const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * c.n_e);
+    switch (w.npass) {
+#define X(NP) case NP: \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_fwd<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_fwd); \
+        hipLaunchKernelGGL(k_tanc_fwd<NP>, grid, blk, w.lds_fwd, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.Pi, R.lw, R.ig, R.Dseq, R.pol, \
+                           R.start, R.clo, w.xbuf, w.flags + w.nflags, w.flags + 2 * w.nflags, w.dpol, w.aggpart); break;
+        NPASS_CASES(X)
 #undef X
     }
+    return hipGetLastError();
 }
 
 // ---- graph construction -----------------------------------------------------------------------
@@ -156,50 +165,59 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     const Consts &c = ctx->c;
     const size_t P = c.P, G = c.G;
     w.N = N;
-    int NC = 1, lg = 0;
-    while (NC < N && NC < 64) { NC <<= 1; lg++; }
-    const int RB = 64 / NC;
-    w.nbx = (c.n_a + RB - 1) / RB;
-    w.g.N = N; w.g.NC = NC; w.g.lgNC = lg; w.g.nbx = w.nbx;
-    const size_t GV = (size_t)(c.n_a + KV) * c.n_e;   // dD state carries KV virtual rows per column
+    // cluster geometry: CS workgroups (one per CU) share one tangent direction; as many clusters as
+    // the chip holds, a cluster loops over its share of the N directions.
+    int cs_min = 1;
+    while ((c.n_a + cs_min - 1) / cs_min > CL_MAXPASS * 64) cs_min <<= 1;
+    int cs = 8;
+    while (cs > 1 && (ctx->n_cu / cs) < N && cs > cs_min) cs >>= 1;   // more directions than clusters: shrink clusters
+    if (cs < cs_min) cs = cs_min;
+    if (cs > ctx->n_cu) return fail(ctx, HANK_ERR_BAD_ARG, "wealth grid too large for the cluster sweep (n_a=%d)", c.n_a);
+    int ncl = ctx->n_cu / cs;
+    if (ncl > N) ncl = N;
+    if (ncl >= 8) ncl -= ncl % 8;
+    w.g.CS = cs; w.g.nclusters = ncl; w.g.RM = (c.n_a + cs - 1) / cs; w.g.xcd_map = (ncl % 8 == 0) ? 1 : 0;
+    int np = (w.g.RM + 63) / 64;
+    w.npass = np <= 1 ? 1 : (np <= 2 ? 2 : (np <= 4 ? 4 : 8));
+    const size_t RP = (size_t)w.npass * 64;
+    // >= 84 KiB of LDS per workgroup: exactly one workgroup per CU (hand-off form requires it)
+    const size_t min_lds = 84 * 1024;
+    w.lds_back = sizeof(double) * c.n_e * RP;
+    w.lds_fwd = sizeof(double) * (2 * c.n_e * RP + 16);
+    if (w.lds_back < min_lds) w.lds_back = min_lds;
+    if (w.lds_fwd < min_lds) w.lds_fwd = min_lds;
+    w.nflags = ncl * cs;
     HIPC(ctx, dmalloc(&w.dxhh, 2 * P * N));
     HIPC(ctx, dmalloc(&w.dxr, P * N));
     HIPC(ctx, dmalloc(&w.dxw, P * N));
-    for (int k = 0; k < 2; k++) {
-        HIPC(ctx, dmalloc(&w.ds[k], G * N));
-        HIPC(ctx, dmalloc(&w.dD[k], GV * N));
-    }
+    HIPC(ctx, dmalloc(&w.xbuf, (size_t)ncl * 2 * G));
+    HIPC(ctx, dmalloc(&w.flags, (size_t)2 * w.nflags + 4));
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)(w.nbx + KV) * N));
+    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)cs * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
 
     hipStream_t s = ctx->own_stream;
     const int PN = (int)(P * N);
-    // backward tangent sweep
+    const int nfl = 2 * w.nflags + 4;
+    // backward tangent sweep: one persistent launch
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_zero_i32, dim3((nfl + 255) / 256), dim3(256), 0, s, (int *)w.flags, nfl);
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    launch_tan_back(ctx, w, (int)P - 1, 1, w.ds[1], w.ds[0], s);
-    int cur = 0;
-    for (int t = (int)P - 1; t >= 0; t--) {
-        launch_tan_back(ctx, w, t, 0, w.ds[cur], w.ds[cur ^ 1], s);
-        cur ^= 1;
-    }
+    hipError_t le = launch_tanc_back(ctx, w, s);
     int rc = end_capture(ctx, &w.g_back);
     if (rc) return rc;
+    HIPC(ctx, le);
     // forward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
-    cur = 0;
-    for (int t = 0; t < (int)P; t++) {
-        launch_tan_fwd(ctx, w, t, w.dD[cur], w.dD[cur ^ 1], s);
-        cur ^= 1;
-    }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, w.nbx + KV, N, w.dagg);
+    le = launch_tanc_fwd(ctx, w, s);
+    hipLaunchKernelGGL(k_tanc_sum, dim3((PN + 255) / 256), dim3(256), 0, s, w.aggpart, (int)P, N, cs, w.dagg);
     hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
     rc = end_capture(ctx, &w.g_fwd);
-    ctx->launches[2] = (int)P + 2;
-    ctx->launches[3] = (int)P + 3;
+    if (rc) return rc;
+    HIPC(ctx, le);
+    ctx->launches[2] = 1;
+    ctx->launches[3] = 1;
     return rc;
 }
 
@@ -227,6 +245,8 @@ static int fetch_device_error(hank_ctx *ctx) {
     }
 }
 
+static int check_tangent_timeout(hank_ctx *ctx);
+
 // ================================ C ABI =========================================================
 extern "C" {
 
@@ -251,6 +271,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, hipGetDevice(&ctx->device));
     hipDeviceProp_t prop;
     HIPC(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    ctx->n_cu = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ctx, HANK_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", ctx->device, prop.gcnArchName);
     Consts &c = ctx->c;
@@ -361,7 +382,9 @@ int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
 
 int hank_check(hank_ctx *ctx) {
     if (!ctx) return HANK_ERR_BAD_ARG;
-    return fetch_device_error(ctx);
+    int rc = fetch_device_error(ctx);
+    if (rc) return rc;
+    return ctx->tw.flags ? check_tangent_timeout(ctx) : HANK_OK;
 }
 
 int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
@@ -380,6 +403,18 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
         HIPC(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+static int check_tangent_timeout(hank_ctx *ctx) {
+    unsigned tmo = 0;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    HIPC(ctx, hipMemcpy(&tmo, ctx->tw.flags + 2 * ctx->tw.nflags, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (tmo) {
+        ctx->tw.valid = false;
+        return fail(ctx, HANK_ERR_NO_DEVICE, "internal error: a cluster hand-off of the tangent sweep timed out "
+                                              "(workgroups of a cluster were not co-resident)");
+    }
     return HANK_OK;
 }
 
@@ -419,6 +454,8 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
     if (rc) return rc;
     HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    rc = check_tangent_timeout(ctx);
+    if (rc) return rc;
     ctx->errmsg[0] = 0;
     return HANK_OK;
 }
@@ -459,15 +496,10 @@ int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
     TanWork &w = ctx->tw;
     if (!w.valid || w.N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
+    // device layout [n][t][e][a] IS the column-major (G, P, N) array
     const size_t total = (size_t)ctx->c.P * ctx->c.G * N;
-    double *tmp = nullptr;
-    HIPC(ctx, dmalloc(&tmp, total));
-    hipLaunchKernelGGL(k_export_dpol, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w.dpol, ctx->c.G, ctx->c.P, N, tmp);
-    hipError_t e1 = hipMemcpyAsync(out, tmp, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream);
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    HIPC(ctx, e1);
-    HIPC(ctx, e2);
+    HIPC(ctx, hipMemcpyAsync(out, w.dpol, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return HANK_OK;
 }
 
