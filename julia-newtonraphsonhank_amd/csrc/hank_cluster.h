@@ -15,9 +15,15 @@
 //     before the workgroup barrier, one lane signals);
 //   - clusters are independent (tangent directions are independent), so there is no grid-wide
 //     synchronisation anywhere; a cluster loops over tangents n = c, c + nclusters, ...
+//   - the per-period linearisation record (~52 B per grid point) is cold in HBM when a period
+//     starts; a run-ahead HELPER wave per workgroup touches the slab's record lines two periods
+//     early with register-free LDS-DMA loads, so the workers' just-in-time coefficient reads are L2
+//     hits and DRAM latency leaves the per-period critical path.
 // Every spin is bounded: on timeout a global word is set and all waits fall through, so the grid
 // always drains (the host then reports an internal error).
 //
+// block = 64*(n_e+1) threads: wave e < n_e <-> productivity column e (lanes <-> wealth rows of the
+// slab, NPASS passes of 64), wave n_e = helper.
 // dpol layout here: [n][t][e][a] (tangent slowest, wealth fastest: lanes run along wealth), which is
 // exactly the column-major (G, P, N) array BackwardIteration returns.
 #pragma once
@@ -28,6 +34,7 @@ namespace hank {
 typedef unsigned long long u64_t;
 constexpr int CL_MAXPASS = 8;            // 64-row passes per member slab (slab <= 512 rows)
 constexpr unsigned CL_SPIN_LIMIT = 1u << 22;
+constexpr int CL_AHEAD = 2;              // periods the helper wave runs ahead
 
 __device__ __forceinline__ void st_sc1(double *p, double x) {
     __hip_atomic_store(reinterpret_cast<u64_t *>(p), (u64_t)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -35,6 +42,28 @@ __device__ __forceinline__ void st_sc1(double *p, double x) {
 __device__ __forceinline__ double ld_sc1(const double *p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight
+// (__syncthreads() would drain vmcnt and put every prefetch on the critical path)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// register-free touch of the cache lines [p, p + bytes): one dword per 128-byte line lands in a
+// scratch LDS row through LDS-DMA; the point is the L2 fill. Whole wave participates.
+__device__ __forceinline__ void touch_lines(const void *p, size_t bytes, int lane, void *lds_scratch) {
+    const char *base = reinterpret_cast<const char *>(reinterpret_cast<size_t>(p) & ~(size_t)127);
+    const size_t span = (reinterpret_cast<size_t>(p) - reinterpret_cast<size_t>(base)) + bytes;
+    const int nlines = (int)((span + 127) >> 7);
+    for (int l0 = 0; l0 < nlines; l0 += 64) {
+        const int l = min(l0 + lane, nlines - 1);   // every lane issues (LDS-DMA wants a full wave)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + ((size_t)l << 7)),
+                                         (__attribute__((address_space(3))) void *)lds_scratch, 4, 0, 0);
+    }
+}
+
+#ifdef HANK_STAMPS
+#define STAMP(k) do { if (dbg && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_[k] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
 struct ClGeom {
     int CS;         // workgroups per cluster (power of two)
@@ -55,64 +84,111 @@ __device__ __forceinline__ void cl_ids(const ClGeom &g, int &cluster, int &membe
     }
 }
 
-// publish (every wave has issued its sc1 stores) + wait for all CS members of the cluster.
-__device__ __forceinline__ void cl_barrier(unsigned *flags, const ClGeom &g, int cluster, int member,
-                                           unsigned epoch, unsigned *timeout) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its sc1 stores
-    __syncthreads();
-    if (g.CS > 1) {
-        if (threadIdx.x == 0)
-            __hip_atomic_store(&flags[cluster * g.CS + member], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x < 64) {
-            const int lane = threadIdx.x;
-            unsigned spins = 0;
-            for (;;) {
-                unsigned v = epoch;
-                if (lane < g.CS)
-                    v = __hip_atomic_load(&flags[cluster * g.CS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all((int)(v - epoch) >= 0)) break;
-                if (++spins > CL_SPIN_LIMIT ||
-                    __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    if (lane == 0) __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+// hand-off, part 1 (worker waves): every storing wave drains its sc1 stores, workgroup barrier, one
+// lane raises this member's epoch flag.
+__device__ __forceinline__ void cl_publish(unsigned *flags, const ClGeom &g, int cluster, int member, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (g.CS > 1 && threadIdx.x == 0)
+        __hip_atomic_store(&flags[cluster * g.CS + member], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// hand-off, part 2: wave 0 polls the CS flags of the cluster (bounded), then the workgroup barrier
+// releases the other waves' sc1 loads.
+__device__ __forceinline__ void cl_wait(unsigned *flags, const ClGeom &g, int cluster, unsigned epoch, unsigned *timeout) {
+    if (g.CS > 1 && threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned spins = 0;
+        for (;;) {
+            unsigned v = epoch;
+            if (lane < g.CS)
+                v = __hip_atomic_load(&flags[cluster * g.CS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((int)(v - epoch) >= 0)) break;
+            if (++spins > CL_SPIN_LIMIT ||
+                ((spins & 255u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (lane == 0) __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
             }
+            __builtin_amdgcn_s_sleep(1);
         }
-        __syncthreads();
     }
+    lds_barrier();
 }
 
 // ---- backward tangent sweep ----------------------------------------------------------------------
-// block = 64*n_e threads (wave e <-> productivity column e, lanes <-> wealth rows of the slab);
-// dynamic LDS: dVsh[n_e][NPASS*64]
+// dynamic LDS: dVsh[n_e][NPASS*64] + 64-dword scratch row for the helper's LDS-DMA touches
 template <int NPASS>
 __global__ void __launch_bounds__(1024)
 k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__restrict__ agrid,
             const double *__restrict__ zg, const double *__restrict__ Pi, TAN_REC_PARAMS,
             const double *__restrict__ dxr, const double *__restrict__ dxw, double *xbuf,
-            unsigned *flags, unsigned *timeout, double *__restrict__ dpol) {
+            unsigned *flags, unsigned *timeout, double *__restrict__ dpol, unsigned long long *dbg) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int RP = NPASS * 64;
     double *dVsh = lds;
+#ifdef HANK_STAMPS
+    unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
+    void *scratch = lds + (size_t)n_e * RP;
     const int lane = threadIdx.x & 63;
     const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool helper = (e == n_e);
     int cluster, member;
     cl_ids(g, cluster, member);
     const int r_lo = member * g.RM;
     const int r_hi = min(n_a, r_lo + g.RM);
-    const double ze = zg[e];
+    const int nrows = max(0, r_hi - r_lo);
     double *xb = xbuf + (size_t)cluster * 2 * G;
     unsigned epoch = 0;
+
+    if (helper) {
+        // run-ahead L2 warmer; mirrors the workers' barrier sequence (3 barriers per period + 1 per tangent)
+        for (int n = cluster; n < N; n += g.nclusters) {
+            lds_barrier();
+            for (int t = P - 1; t >= 0; t--) {
+                const int tp = t - CL_AHEAD;
+                if (tp >= 0 && nrows > 0) {
+                    for (int e2 = 0; e2 < n_e; e2++) {
+                        const size_t o = (size_t)tp * G + (size_t)e2 * n_a + r_lo;
+                        touch_lines(ib + o, (size_t)nrows * 4, lane, scratch);
+                        touch_lines(rA + o, (size_t)nrows * 8, lane, scratch);
+                        touch_lines(rB + o, (size_t)nrows * 8, lane, scratch);
+                        touch_lines(ru + o, (size_t)nrows * 8, lane, scratch);
+                        touch_lines(rv + o, (size_t)nrows * 8, lane, scratch);
+                        touch_lines(rkc + o, (size_t)nrows * 8, lane, scratch);
+                        touch_lines(rs + o, (size_t)nrows * 8, lane, scratch);
+                    }
+                }
+                lds_barrier();   // cl_publish
+                lds_barrier();   // cl_wait
+                lds_barrier();   // end of period
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    const double ze = zg[e];
     for (int n = cluster; n < N; n += g.nclusters) {
 #pragma unroll
         for (int p = 0; p < NPASS; p++) dVsh[e * RP + p * 64 + lane] = 0.0;   // dV_T = 0 (BackwardIteration.jl:85)
-        __syncthreads();
         double *dpn = dpol + (size_t)n * P * G;
+        // knot coefficients of the first period
+        double xk[NPASS], xs[NPASS];
+        {
+            const size_t tb = (size_t)(P - 1) * G + (size_t)e * n_a;
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                const int a = r_lo + p * 64 + lane;
+                xk[p] = 0.0; xs[p] = 0.0;
+                if (a < r_hi) { xk[p] = rkc[tb + a]; xs[p] = rs[tb + a]; }
+            }
+        }
+        lds_barrier();
         for (int t = P - 1; t >= 0; t--) {
             const size_t tb = (size_t)t * G + (size_t)e * n_a;
             const double dr = dxr[(size_t)t * N + n], dw = dxw[(size_t)t * N + n], rh = rho[t];
             double *xe = xb + (size_t)(t & 1) * G + (size_t)e * n_a;
+            STAMP(0);
             // X half of period t: mix dV_{t+1} over e -> knot tangents of my slab, published sc1
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
@@ -120,66 +196,130 @@ k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__res
                 if (a < r_hi) {
                     double dE = dVsh[rl] * Pi[e];
                     for (int e2 = 1; e2 < n_e; e2++) dE += dVsh[e2 * RP + rl] * Pi[e + n_e * e2];
-                    st_sc1(&xe[a], rkc[tb + a] * dE - rh * (ze * dw + rs[tb + a] * dr));
+                    st_sc1(&xe[a], xk[p] * dE - rh * (ze * dw + xs[p] * dr));
                 }
             }
-            // Y-half coefficients do not depend on the peers: fetch them while the hand-off settles
+            STAMP(1);
+            cl_publish(flags, g, cluster, member, ++epoch);
+            STAMP(2);
+            // peer-independent coefficient reads ride under the flag poll (L2-warm thanks to the helper):
+            // Y half of this period, knots of the next one
             int ci[NPASS];
             double cA[NPASS], cB[NPASS], cu[NPASS], cv[NPASS], cx[NPASS];
+            const size_t tb1 = t > 0 ? tb - G : tb;
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
                 const int a = r_lo + p * 64 + lane;
+                ci[p] = 0;
                 if (a < r_hi) {
                     ci[p] = ib[tb + a]; cA[p] = rA[tb + a]; cB[p] = rB[tb + a];
                     cu[p] = ru[tb + a]; cv[p] = rv[tb + a]; cx[p] = agrid[a];
+                    xk[p] = rkc[tb1 + a]; xs[p] = rs[tb1 + a];
                 }
             }
-            cl_barrier(flags, g, cluster, member, ++epoch, timeout);
+            STAMP(3);
+            cl_wait(flags, g, cluster, epoch, timeout);
+            STAMP(4);
             // Y half: bracket gather from the cluster's exchange tile
+            double d0[NPASS], d1[NPASS];
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                const int a = r_lo + p * 64 + lane;
+                if (a < r_hi) { d0[p] = ld_sc1(&xe[ci[p]]); d1[p] = ld_sc1(&xe[ci[p] + 1]); }
+            }
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
                 const int rl = p * 64 + lane, a = r_lo + rl;
                 if (a < r_hi) {
-                    const double ds0 = ld_sc1(&xe[ci[p]]), ds1 = ld_sc1(&xe[ci[p] + 1]);
-                    const double dg = cA[p] * ds0 + cB[p] * ds1;
+                    const double dg = cA[p] * d0[p] + cB[p] * d1[p];
                     dpn[tb + a] = dg;
                     dVsh[e * RP + rl] = cu[p] * dr + cv[p] * ((cx[p] * dr + ze * dw) - dg);
                 }
             }
-            __syncthreads();
+            STAMP(5);
+            lds_barrier();
+            STAMP(6);
         }
     }
+#ifdef HANK_STAMPS
+    if (dbg && threadIdx.x == 0)
+        for (int k = 0; k < 8; k++) dbg[blockIdx.x * 8 + k] = acc_[k];
+#endif
 }
 
 // ---- forward tangent sweep -----------------------------------------------------------------------
-// dynamic LDS: dDsh[n_e][RP] + midsh[n_e][RP] + red[16]
+// dynamic LDS: dDsh[n_e][RP] + midsh[n_e][RP] + red[16] + scratch row
 template <int NPASS>
 __global__ void __launch_bounds__(1024)
 k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__restrict__ Pi,
-           const double *__restrict__ lw, const double *__restrict__ ig, const double *__restrict__ Dseq,
-           const double *__restrict__ pol, const int *__restrict__ start, const int *__restrict__ clo_,
-           double *xbuf, unsigned *flags, unsigned *timeout, const double *__restrict__ dpol,
-           double *__restrict__ aggpart /* [N][P][CS] */) {
+           const double *__restrict__ lw, const double *__restrict__ gD /* ig * D_{t-1} */,
+           const double *__restrict__ Dseq, const double *__restrict__ pol, const int *__restrict__ start,
+           const int *__restrict__ clo_, double *xbuf, unsigned *flags, unsigned *timeout,
+           const double *__restrict__ dpol, double *__restrict__ aggpart /* [N][P][CS] */) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int RP = NPASS * 64;
     double *dDsh = lds, *midsh = lds + (size_t)n_e * RP, *red = midsh + (size_t)n_e * RP;
+    void *scratch = red + 16;
     const int lane = threadIdx.x & 63;
     const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool helper = (e == n_e);
     int cluster, member;
     cl_ids(g, cluster, member);
     const int r_lo = member * g.RM;
     const int r_hi = min(n_a, r_lo + g.RM);
+    const int nrows = max(0, r_hi - r_lo);
     double *xb = xbuf + (size_t)cluster * 2 * G;
     unsigned epoch = 0;
+
+    if (helper) {
+        // barrier sequence per period: publish, wait, gather->mix, 2 inside the block reduction
+        for (int n = cluster; n < N; n += g.nclusters) {
+            const double *dpn = dpol + (size_t)n * P * G;
+            lds_barrier();
+            for (int t = 0; t < P; t++) {
+                const int tp = t + CL_AHEAD;
+                if (tp < P && nrows > 0) {
+                    // lane e2 reads the source range of column e2 for period tp (the record of `start`
+                    // is small and re-read by every cluster: L2/MALL resident after the first sweep)
+                    int sLo = 0, sHi = 0;
+                    if (lane < n_e) {
+                        const int *st = start + ((size_t)tp * n_e + lane) * (n_a + 1);
+                        sLo = st[r_lo > 0 ? r_lo - 1 : 0];
+                        sHi = st[r_hi];
+                    }
+                    for (int e2 = 0; e2 < n_e; e2++) {
+                        const int lo = __shfl(sLo, e2, 64), hi = __shfl(sHi, e2, 64);
+                        const size_t oc = (size_t)tp * G + (size_t)e2 * n_a;
+                        if (hi > lo) {
+                            touch_lines(lw + oc + lo, (size_t)(hi - lo) * 8, lane, scratch);
+                            touch_lines(gD + oc + lo, (size_t)(hi - lo) * 8, lane, scratch);
+                            touch_lines(dpn + oc + lo, (size_t)(hi - lo) * 8, lane, scratch);
+                        }
+                        touch_lines(pol + oc + r_lo, (size_t)nrows * 8, lane, scratch);
+                        touch_lines(Dseq + oc + G + r_lo, (size_t)nrows * 8, lane, scratch);
+                        touch_lines(dpn + oc + r_lo, (size_t)nrows * 8, lane, scratch);
+                    }
+                }
+                lds_barrier();   // cl_publish
+                lds_barrier();   // cl_wait
+                lds_barrier();   // midsh complete
+                lds_barrier();   // block reduction (1)
+                lds_barrier();   // block reduction (2)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
     for (int n = cluster; n < N; n += g.nclusters) {
 #pragma unroll
         for (int p = 0; p < NPASS; p++) dDsh[e * RP + p * 64 + lane] = 0.0;   // dD_0 = 0 (ForwardIteration.jl:293)
-        __syncthreads();
         const double *dpn = dpol + (size_t)n * P * G;
+        lds_barrier();
         for (int t = 0; t < P; t++) {
             const size_t tb = (size_t)t * G + (size_t)e * n_a;
             double *xe = xb + (size_t)(t & 1) * G + (size_t)e * n_a;
-            const double *Dprev = Dseq + tb, *Dnew = Dseq + tb + G;
+            const double *Dnew = Dseq + tb + G;
             const int *st = start + ((size_t)t * n_e + e) * (n_a + 1);
             // publish dD_{t-1} of my slab
 #pragma unroll
@@ -187,17 +327,21 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
                 const int rl = p * 64 + lane, a = r_lo + rl;
                 if (a < r_hi) st_sc1(&xe[a], dDsh[e * RP + rl]);
             }
-            // peer-independent loads first
+            cl_publish(flags, g, cluster, member, ++epoch);
+            // peer-independent reads under the flag poll
             int s0[NPASS], s1[NPASS], s2[NPASS];
+            double cp[NPASS], cDn[NPASS], cdp[NPASS];
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
                 const int r = r_lo + p * 64 + lane;
+                s0[p] = s1[p] = s2[p] = 0;
                 if (r < r_hi) {
                     s1[p] = st[r]; s2[p] = st[r + 1]; s0[p] = r > 0 ? st[r - 1] : s1[p];
+                    cp[p] = pol[tb + r]; cDn[p] = Dnew[r]; cdp[p] = dpn[tb + r];
                 }
             }
             const int clo = clo_[(size_t)t * n_e + e];
-            cl_barrier(flags, g, cluster, member, ++epoch, timeout);
+            cl_wait(flags, g, cluster, epoch, timeout);
             // lottery-segment gather of my target rows
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
@@ -205,9 +349,9 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
                 if (r < r_hi) {
                     double acc = 0.0;
                     for (int j = s0[p]; j < s1[p]; j++)
-                        acc += lw[tb + j] * ld_sc1(&xe[j]) + (dpn[tb + j] * ig[tb + j]) * Dprev[j];
+                        acc += lw[tb + j] * ld_sc1(&xe[j]) + dpn[tb + j] * gD[tb + j];
                     for (int j = s1[p]; j < s2[p]; j++)
-                        acc += (1.0 - lw[tb + j]) * ld_sc1(&xe[j]) - (dpn[tb + j] * ig[tb + j]) * Dprev[j];
+                        acc += (1.0 - lw[tb + j]) * ld_sc1(&xe[j]) - dpn[tb + j] * gD[tb + j];
                     midsh[e * RP + rl] = acc;
                 }
             }
@@ -217,7 +361,7 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
                 s = wave_sum(s);
                 if (lane == 0) midsh[e * RP] += s;
             }
-            __syncthreads();
+            lds_barrier();
             double part = 0.0;
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
@@ -226,11 +370,19 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
                     double dDn = midsh[rl] * Pi[n_e * e];      // dD_t[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
                     for (int k = 1; k < n_e; k++) dDn += midsh[k * RP + rl] * Pi[k + n_e * e];
                     dDsh[e * RP + rl] = dDn;
-                    part += pol[tb + r] * dDn + dpn[tb + r] * Dnew[r];
+                    part += cp[p] * dDn + cdp[p] * cDn[p];
                 }
             }
-            const double tot = block_sum(part, red);     // (contains the barriers that fence midsh/dDsh reuse)
-            if (threadIdx.x == 0) aggpart[((size_t)n * P + t) * g.CS + member] = tot;
+            // block reduction of the aggregate term over the n_e worker waves (fixed order)
+            part = wave_sum(part);
+            lds_barrier();
+            if (lane == 0) red[e] = part;
+            lds_barrier();
+            if (threadIdx.x == 0) {
+                double tot = 0.0;
+                for (int k = 0; k < n_e; k++) tot += red[k];
+                aggpart[((size_t)n * P + t) * g.CS + member] = tot;
+            }
         }
     }
 }

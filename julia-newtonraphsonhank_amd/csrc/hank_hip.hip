@@ -30,6 +30,7 @@ struct TanWork {
     double *dagg = nullptr;     // [P][N]
     double *dagg_cm = nullptr;  // (P,N) column-major
     int nflags = 0;
+    unsigned long long *dbg = nullptr;  // per-workgroup phase stamps (diagnostic builds only)
     hipGraphExec_t g_back = nullptr, g_fwd = nullptr;
     bool valid = false;  // dpol holds the partials of the current primal
 };
@@ -84,7 +85,7 @@ static size_t primal_lds(const Consts &c) { return sizeof(double) * ((size_t)c.n
 static void free_tanwork(TanWork &w) {
     if (w.g_back) (void)hipGraphExecDestroy(w.g_back);
     if (w.g_fwd) (void)hipGraphExecDestroy(w.g_fwd);
-    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw); (void)hipFree(w.xbuf); (void)hipFree(w.flags);
+    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw); (void)hipFree(w.xbuf); (void)hipFree(w.flags); (void)hipFree(w.dbg);
     (void)hipFree(w.dpol); (void)hipFree(w.aggpart); (void)hipFree(w.dagg); (void)hipFree(w.dagg_cm);
     w = TanWork();
 }
@@ -94,12 +95,12 @@ static void free_tanwork(TanWork &w) {
 
 static hipError_t launch_tanc_back(hank_ctx *ctx, TanWork &w, hipStream_t s) {
     const Consts &c = ctx->c;
-    const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * c.n_e);
+    const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * (c.n_e + 1));
     switch (w.npass) {
 #define X(NP) case NP: \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_back<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_back); \
         hipLaunchKernelGGL(k_tanc_back<NP>, grid, blk, w.lds_back, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.a, c.z, c.Pi, \
-                           TAN_REC_ARGS(ctx->R, ctx->d_rho), w.dxr, w.dxw, w.xbuf, w.flags, w.flags + 2 * w.nflags, w.dpol); break;
+                           TAN_REC_ARGS(ctx->R, ctx->d_rho), w.dxr, w.dxw, w.xbuf, w.flags, w.flags + 2 * w.nflags, w.dpol, w.dbg); break;
         NPASS_CASES(X)
 #undef X
     }
@@ -108,11 +109,11 @@ static hipError_t launch_tanc_back(hank_ctx *ctx, TanWork &w, hipStream_t s) {
 static hipError_t launch_tanc_fwd(hank_ctx *ctx, TanWork &w, hipStream_t s) {
     const Consts &c = ctx->c;
     const Record &R = ctx->R;
-    const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * c.n_e);
+    const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * (c.n_e + 1));
     switch (w.npass) {
 #define X(NP) case NP: \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_fwd<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_fwd); \
-        hipLaunchKernelGGL(k_tanc_fwd<NP>, grid, blk, w.lds_fwd, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.Pi, R.lw, R.ig, R.Dseq, R.pol, \
+        hipLaunchKernelGGL(k_tanc_fwd<NP>, grid, blk, w.lds_fwd, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.Pi, R.lw, R.gD, R.Dseq, R.pol, \
                            R.start, R.clo, w.xbuf, w.flags + w.nflags, w.flags + 2 * w.nflags, w.dpol, w.aggpart); break;
         NPASS_CASES(X)
 #undef X
@@ -182,8 +183,8 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     const size_t RP = (size_t)w.npass * 64;
     // >= 84 KiB of LDS per workgroup: exactly one workgroup per CU (hand-off form requires it)
     const size_t min_lds = 84 * 1024;
-    w.lds_back = sizeof(double) * c.n_e * RP;
-    w.lds_fwd = sizeof(double) * (2 * c.n_e * RP + 16);
+    w.lds_back = sizeof(double) * c.n_e * RP + 256;
+    w.lds_fwd = sizeof(double) * (2 * c.n_e * RP + 16) + 256;
     if (w.lds_back < min_lds) w.lds_back = min_lds;
     if (w.lds_fwd < min_lds) w.lds_fwd = min_lds;
     w.nflags = ncl * cs;
@@ -195,6 +196,9 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
     HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)cs * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
+#ifdef HANK_STAMPS
+    HIPC(ctx, dmalloc(&w.dbg, (size_t)ncl * cs * 8));
+#endif
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
 
     hipStream_t s = ctx->own_stream;
@@ -261,8 +265,8 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     hank_ctx *ctx = new (std::nothrow) hank_ctx();
     if (!ctx) return HANK_ERR_NOMEM;
     *out = ctx;  // returned even on failure so the caller can read hank_last_error, then destroy
-    if (m->n_a < 2 || m->n_e < 1 || m->n_e > 16 || m->T < 2)
-        return fail(ctx, HANK_ERR_BAD_ARG, "bad shape: n_a=%d (>=2), n_e=%d (1..16), T=%d (>=2)", m->n_a, m->n_e, m->T);
+    if (m->n_a < 2 || m->n_e < 1 || m->n_e > 15 || m->T < 2)
+        return fail(ctx, HANK_ERR_BAD_ARG, "bad shape: n_a=%d (>=2), n_e=%d (1..15), T=%d (>=2)", m->n_a, m->n_e, m->T);
     if (m->value_fn_id != HANK_VF_KRUSELL_SMITH)
         return fail(ctx, HANK_ERR_BAD_ARG, "unknown value function id %d", m->value_fn_id);
     if (!m->a_grid || !m->z_grid || !m->Pi) return fail(ctx, HANK_ERR_BAD_ARG, "null grid pointer");
@@ -295,7 +299,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, dmalloc(&R.A, P * G)); HIPC(ctx, dmalloc(&R.B, P * G));
     HIPC(ctx, dmalloc(&R.u, P * G)); HIPC(ctx, dmalloc(&R.v, P * G));
     HIPC(ctx, dmalloc(&R.pol, P * G)); HIPC(ctx, dmalloc(&R.lw, P * G));
-    HIPC(ctx, dmalloc(&R.ig, P * G)); HIPC(ctx, dmalloc(&R.Dseq, (P + 1) * G));
+    HIPC(ctx, dmalloc(&R.ig, P * G)); HIPC(ctx, dmalloc(&R.gD, P * G)); HIPC(ctx, dmalloc(&R.Dseq, (P + 1) * G));
     HIPC(ctx, dmalloc(&R.ib, P * G)); HIPC(ctx, dmalloc(&R.lo, P * G));
     HIPC(ctx, dmalloc(&R.start, P * (size_t)c.n_e * (c.n_a + 1)));
     HIPC(ctx, dmalloc(&R.clo, P * (size_t)c.n_e));
@@ -322,7 +326,7 @@ int hank_destroy(hank_ctx *ctx) {
     if (ctx->g_pfwd) (void)hipGraphExecDestroy(ctx->g_pfwd);
     Record &R = ctx->R;
     (void)hipFree(R.s); (void)hipFree(R.kc); (void)hipFree(R.A); (void)hipFree(R.B); (void)hipFree(R.u); (void)hipFree(R.v);
-    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo);
+    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.gD); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
     (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_rho); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 8; k++)
@@ -623,3 +627,14 @@ int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dp
 }
 
 }  // extern "C"
+
+#ifdef HANK_STAMPS
+extern "C" int hank_debug_stamps(hank_ctx *ctx, unsigned long long *out, int max_wg) {
+    TanWork &w = ctx->tw;
+    int n = w.g.nclusters * w.g.CS;
+    if (n > max_wg) n = max_wg;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(out, w.dbg, sizeof(unsigned long long) * n * 8, hipMemcpyDeviceToHost);
+    return n;
+}
+#endif

@@ -28,7 +28,7 @@ struct Consts {
 };
 
 struct Record {
-    double *s, *kc, *A, *B, *u, *v, *pol, *lw, *ig, *Dseq;
+    double *s, *kc, *A, *B, *u, *v, *pol, *lw, *ig, *gD, *Dseq;
     int *ib, *lo, *start, *clo;
 };
 
@@ -261,6 +261,7 @@ __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
     const double *lw = R.lw + base + (size_t)e * n, *Dp = Dprev + (size_t)e * n;
     double acc = 0.0;
     if (r < n) {
+        R.gD[base + (size_t)e * n + r] = R.ig[base + (size_t)e * n + r] * Dp[r];   // weight-tangent factor of source row r
         const int *st = R.start + ((size_t)t * c.n_e + e) * (n + 1);
         const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
         for (int j = st0; j < st1; j++) acc += lw[j] * Dp[j];
