@@ -84,51 +84,65 @@ __device__ __forceinline__ void cl_ids(const ClGeom &g, int &cluster, int &membe
     }
 }
 
-// hand-off, part 1 (worker waves): every storing wave drains its sc1 stores, workgroup barrier, one
-// lane raises this member's epoch flag.
-__device__ __forceinline__ void cl_publish(unsigned *flags, const ClGeom &g, int cluster, int member, unsigned epoch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    if (g.CS > 1 && threadIdx.x == 0)
-        __hip_atomic_store(&flags[cluster * g.CS + member], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// ---- the hand-off: data-tagged granules (Guideline 16, R2 form) -----------------------------------
+// A published double travels as TWO naturally aligned 8-byte words {tag:32 | hi:32}, {tag:32 | lo:32},
+// each written by one sc1 (write-through) store and read by one sc1 (L1-bypassing) load: every word
+// is single-copy atomic and carries its own tag, so the data IS the flag — no drain, no workgroup
+// barrier, no flag round trip on the per-period critical path. tag = running period count + 1 (never
+// 0; the exchange ring is zeroed before every launch). A consumer re-reads until both tags match.
+// The exchange tile is a ring of CL_RING period slots; before a member overwrites a slot it checks
+// (off the critical path: the loads are issued a period early) that every member has finished
+// reading the period that lived there (per-member `done` counters).
+constexpr int CL_RING = 4;
+
+__device__ __forceinline__ void st_gran(u64_t *g, unsigned tag, double x) {
+    const u64_t b = (u64_t)__double_as_longlong(x), tg = (u64_t)tag << 32;
+    __hip_atomic_store(g, tg | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, tg | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// hand-off, part 2: wave 0 polls the CS flags of the cluster (bounded), then the workgroup barrier
-// releases the other waves' sc1 loads.
-__device__ __forceinline__ void cl_wait(unsigned *flags, const ClGeom &g, int cluster, unsigned epoch, unsigned *timeout) {
-    if (g.CS > 1 && threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        unsigned spins = 0;
-        for (;;) {
-            unsigned v = epoch;
-            if (lane < g.CS)
-                v = __hip_atomic_load(&flags[cluster * g.CS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all((int)(v - epoch) >= 0)) break;
-            if (++spins > CL_SPIN_LIMIT ||
-                ((spins & 255u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                if (lane == 0) __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
+__device__ __forceinline__ bool ld_gran(const u64_t *g, unsigned tag, double &x) {
+    const u64_t h = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64_t l = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = __longlong_as_double((long long)(((h & 0xffffffffull) << 32) | (l & 0xffffffffull)));
+    return ((unsigned)(h >> 32) == tag) & ((unsigned)(l >> 32) == tag);
+}
+__device__ __forceinline__ bool cl_timed_out(unsigned &spins, unsigned *timeout) {
+    if (++spins > CL_SPIN_LIMIT ||
+        ((spins & 1023u) == 0u && __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
     }
-    lds_barrier();
+    return false;
+}
+// back-pressure: every member of the cluster has completed `need` periods (wave-level check)
+__device__ __forceinline__ void cl_ring_ready(const unsigned *done, const ClGeom &g, int cluster, int lane, int need,
+                                              unsigned *timeout) {
+    if (g.CS == 1 || need <= 0) return;
+    unsigned spins = 0;
+    for (;;) {
+        int v = need;
+        if (lane < g.CS) v = (int)__hip_atomic_load(&done[cluster * g.CS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v - need >= 0)) return;
+        if (cl_timed_out(spins, timeout)) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
 }
 
 // ---- backward tangent sweep ----------------------------------------------------------------------
 // dynamic LDS: dVsh[n_e][NPASS*64] + 64-dword scratch row for the helper's LDS-DMA touches
-template <int NPASS>
-__global__ void __launch_bounds__(1024)
+template <int NPASS, int MAXT>
+__global__ void __launch_bounds__(MAXT)
 k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__restrict__ agrid,
             const double *__restrict__ zg, const double *__restrict__ Pi, TAN_REC_PARAMS,
-            const double *__restrict__ dxr, const double *__restrict__ dxw, double *xbuf,
-            unsigned *flags, unsigned *timeout, double *__restrict__ dpol, unsigned long long *dbg) {
+            const double *__restrict__ dxr, const double *__restrict__ dxw, u64_t *xbuf,
+            unsigned *done, unsigned *timeout, double *__restrict__ dpol, unsigned long long *dbg) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int RP = NPASS * 64;
     double *dVsh = lds;
+    void *scratch = lds + (size_t)n_e * RP;
 #ifdef HANK_STAMPS
     unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
-    void *scratch = lds + (size_t)n_e * RP;
     const int lane = threadIdx.x & 63;
     const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool helper = (e == n_e);
@@ -137,11 +151,10 @@ k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__res
     const int r_lo = member * g.RM;
     const int r_hi = min(n_a, r_lo + g.RM);
     const int nrows = max(0, r_hi - r_lo);
-    double *xb = xbuf + (size_t)cluster * 2 * G;
-    unsigned epoch = 0;
+    u64_t *xb = xbuf + (size_t)cluster * CL_RING * G * 2;
 
     if (helper) {
-        // run-ahead L2 warmer; mirrors the workers' barrier sequence (3 barriers per period + 1 per tangent)
+        // run-ahead L2 warmer; mirrors the workers' barrier sequence (2 per period + 1 per tangent)
         for (int n = cluster; n < N; n += g.nclusters) {
             lds_barrier();
             for (int t = P - 1; t >= 0; t--) {
@@ -158,8 +171,7 @@ k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__res
                         touch_lines(rs + o, (size_t)nrows * 8, lane, scratch);
                     }
                 }
-                lds_barrier();   // cl_publish
-                lds_barrier();   // cl_wait
+                lds_barrier();   // X reads of dVsh done
                 lds_barrier();   // end of period
             }
         }
@@ -168,12 +180,15 @@ k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__res
     }
 
     const double ze = zg[e];
+    double pir[16];   // row e of Pi, wave-constant
+#pragma unroll
+    for (int k = 0; k < 16; k++) pir[k] = k < n_e ? Pi[e + n_e * k] : 0.0;
+    int q = 0;        // running period count of this cluster (tag = q + 1)
     for (int n = cluster; n < N; n += g.nclusters) {
 #pragma unroll
         for (int p = 0; p < NPASS; p++) dVsh[e * RP + p * 64 + lane] = 0.0;   // dV_T = 0 (BackwardIteration.jl:85)
         double *dpn = dpol + (size_t)n * P * G;
-        // knot coefficients of the first period
-        double xk[NPASS], xs[NPASS];
+        double xk[NPASS], xs[NPASS];   // knot coefficients of the period being published
         {
             const size_t tb = (size_t)(P - 1) * G + (size_t)e * n_a;
 #pragma unroll
@@ -184,49 +199,68 @@ k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__res
             }
         }
         lds_barrier();
-        for (int t = P - 1; t >= 0; t--) {
+        for (int t = P - 1; t >= 0; t--, q++) {
+            const unsigned tag = (unsigned)q + 1u;
             const size_t tb = (size_t)t * G + (size_t)e * n_a;
             const double dr = dxr[(size_t)t * N + n], dw = dxw[(size_t)t * N + n], rh = rho[t];
-            double *xe = xb + (size_t)(t & 1) * G + (size_t)e * n_a;
+            u64_t *xe = xb + ((size_t)(q % CL_RING) * G + (size_t)e * n_a) * 2;
             STAMP(0);
-            // X half of period t: mix dV_{t+1} over e -> knot tangents of my slab, published sc1
-#pragma unroll
-            for (int p = 0; p < NPASS; p++) {
-                const int rl = p * 64 + lane, a = r_lo + rl;
-                if (a < r_hi) {
-                    double dE = dVsh[rl] * Pi[e];
-                    for (int e2 = 1; e2 < n_e; e2++) dE += dVsh[e2 * RP + rl] * Pi[e + n_e * e2];
-                    st_sc1(&xe[a], xk[p] * dE - rh * (ze * dw + xs[p] * dr));
-                }
-            }
-            STAMP(1);
-            cl_publish(flags, g, cluster, member, ++epoch);
-            STAMP(2);
-            // peer-independent coefficient reads ride under the flag poll (L2-warm thanks to the helper):
-            // Y half of this period, knots of the next one
+            // every peer-independent read of this period, issued up front: Y-half coefficients of period
+            // t and the knot coefficients of period t-1 (L2-warm thanks to the helper)
             int ci[NPASS];
-            double cA[NPASS], cB[NPASS], cu[NPASS], cv[NPASS], cx[NPASS];
+            double cA[NPASS], cB[NPASS], cu[NPASS], cv[NPASS], cx[NPASS], nk[NPASS], ns[NPASS];
             const size_t tb1 = t > 0 ? tb - G : tb;
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
                 const int a = r_lo + p * 64 + lane;
-                ci[p] = 0;
+                ci[p] = 0; nk[p] = 0.0; ns[p] = 0.0;
                 if (a < r_hi) {
                     ci[p] = ib[tb + a]; cA[p] = rA[tb + a]; cB[p] = rB[tb + a];
                     cu[p] = ru[tb + a]; cv[p] = rv[tb + a]; cx[p] = agrid[a];
-                    xk[p] = rkc[tb1 + a]; xs[p] = rs[tb1 + a];
+                    nk[p] = rkc[tb1 + a]; ns[p] = rs[tb1 + a];
                 }
             }
-            STAMP(3);
-            cl_wait(flags, g, cluster, epoch, timeout);
-            STAMP(4);
-            // Y half: bracket gather from the cluster's exchange tile
-            double d0[NPASS], d1[NPASS];
+            // X half of period t: mix dV_{t+1} over e -> knot tangents of my slab
+            double dsv[NPASS];
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                const int rl = p * 64 + lane;
+                double dE = 0.0;
+#pragma unroll
+                for (int e2 = 0; e2 < 16; e2++)
+                    if (e2 < n_e) dE += dVsh[e2 * RP + rl] * pir[e2];
+                dsv[p] = xk[p] * dE - rh * (ze * dw + xs[p] * dr);
+            }
+            STAMP(1);
+            cl_ring_ready(done, g, cluster, lane, q - (CL_RING - 1), timeout);
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
                 const int a = r_lo + p * 64 + lane;
-                if (a < r_hi) { d0[p] = ld_sc1(&xe[ci[p]]); d1[p] = ld_sc1(&xe[ci[p] + 1]); }
+                if (a < r_hi) st_gran(&xe[2 * (size_t)a], tag, dsv[p]);
             }
+            STAMP(2);
+            lds_barrier();   // all X reads of dVsh are done before any Y write
+            STAMP(3);
+            // Y half: bracket gather from the cluster's exchange ring; re-read until the tags are current
+            double d0[NPASS], d1[NPASS];
+            {
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+#pragma unroll
+                    for (int p = 0; p < NPASS; p++) {
+                        const int a = r_lo + p * 64 + lane;
+                        if (a < r_hi) {
+                            ok &= ld_gran(&xe[2 * (size_t)ci[p]], tag, d0[p]);
+                            ok &= ld_gran(&xe[2 * (size_t)(ci[p] + 1)], tag, d1[p]);
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (cl_timed_out(spins, timeout)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            STAMP(4);
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
                 const int rl = p * 64 + lane, a = r_lo + rl;
@@ -235,9 +269,12 @@ k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__res
                     dpn[tb + a] = dg;
                     dVsh[e * RP + rl] = cu[p] * dr + cv[p] * ((cx[p] * dr + ze * dw) - dg);
                 }
+                xk[p] = nk[p]; xs[p] = ns[p];
             }
             STAMP(5);
             lds_barrier();
+            if (g.CS > 1 && threadIdx.x == 0)   // every wave of this workgroup has finished reading period q
+                __hip_atomic_store(&done[cluster * g.CS + member], (unsigned)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             STAMP(6);
         }
     }
@@ -249,12 +286,12 @@ k_tanc_back(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__res
 
 // ---- forward tangent sweep -----------------------------------------------------------------------
 // dynamic LDS: dDsh[n_e][RP] + midsh[n_e][RP] + red[16] + scratch row
-template <int NPASS>
-__global__ void __launch_bounds__(1024)
+template <int NPASS, int MAXT>
+__global__ void __launch_bounds__(MAXT)
 k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__restrict__ Pi,
            const double *__restrict__ lw, const double *__restrict__ gD /* ig * D_{t-1} */,
            const double *__restrict__ Dseq, const double *__restrict__ pol, const int *__restrict__ start,
-           const int *__restrict__ clo_, double *xbuf, unsigned *flags, unsigned *timeout,
+           const int *__restrict__ clo_, u64_t *xbuf, unsigned *done, unsigned *timeout,
            const double *__restrict__ dpol, double *__restrict__ aggpart /* [N][P][CS] */) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int RP = NPASS * 64;
@@ -268,19 +305,16 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
     const int r_lo = member * g.RM;
     const int r_hi = min(n_a, r_lo + g.RM);
     const int nrows = max(0, r_hi - r_lo);
-    double *xb = xbuf + (size_t)cluster * 2 * G;
-    unsigned epoch = 0;
+    u64_t *xb = xbuf + (size_t)cluster * CL_RING * G * 2;
 
     if (helper) {
-        // barrier sequence per period: publish, wait, gather->mix, 2 inside the block reduction
+        // barrier sequence per period: gather->mix, 2 inside the block reduction
         for (int n = cluster; n < N; n += g.nclusters) {
             const double *dpn = dpol + (size_t)n * P * G;
             lds_barrier();
             for (int t = 0; t < P; t++) {
                 const int tp = t + CL_AHEAD;
                 if (tp < P && nrows > 0) {
-                    // lane e2 reads the source range of column e2 for period tp (the record of `start`
-                    // is small and re-read by every cluster: L2/MALL resident after the first sweep)
                     int sLo = 0, sHi = 0;
                     if (lane < n_e) {
                         const int *st = start + ((size_t)tp * n_e + lane) * (n_a + 1);
@@ -300,8 +334,6 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
                         touch_lines(dpn + oc + r_lo, (size_t)nrows * 8, lane, scratch);
                     }
                 }
-                lds_barrier();   // cl_publish
-                lds_barrier();   // cl_wait
                 lds_barrier();   // midsh complete
                 lds_barrier();   // block reduction (1)
                 lds_barrier();   // block reduction (2)
@@ -311,24 +343,22 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
         return;
     }
 
+    double pic[16];   // column e of Pi: dD_t[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
+#pragma unroll
+    for (int k = 0; k < 16; k++) pic[k] = k < n_e ? Pi[k + n_e * e] : 0.0;
+    int q = 0;
     for (int n = cluster; n < N; n += g.nclusters) {
 #pragma unroll
         for (int p = 0; p < NPASS; p++) dDsh[e * RP + p * 64 + lane] = 0.0;   // dD_0 = 0 (ForwardIteration.jl:293)
         const double *dpn = dpol + (size_t)n * P * G;
         lds_barrier();
-        for (int t = 0; t < P; t++) {
+        for (int t = 0; t < P; t++, q++) {
+            const unsigned tag = (unsigned)q + 1u;
             const size_t tb = (size_t)t * G + (size_t)e * n_a;
-            double *xe = xb + (size_t)(t & 1) * G + (size_t)e * n_a;
+            u64_t *xe = xb + ((size_t)(q % CL_RING) * G + (size_t)e * n_a) * 2;
             const double *Dnew = Dseq + tb + G;
             const int *st = start + ((size_t)t * n_e + e) * (n_a + 1);
-            // publish dD_{t-1} of my slab
-#pragma unroll
-            for (int p = 0; p < NPASS; p++) {
-                const int rl = p * 64 + lane, a = r_lo + rl;
-                if (a < r_hi) st_sc1(&xe[a], dDsh[e * RP + rl]);
-            }
-            cl_publish(flags, g, cluster, member, ++epoch);
-            // peer-independent reads under the flag poll
+            // peer-independent reads first
             int s0[NPASS], s1[NPASS], s2[NPASS];
             double cp[NPASS], cDn[NPASS], cdp[NPASS];
 #pragma unroll
@@ -341,23 +371,43 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
                 }
             }
             const int clo = clo_[(size_t)t * n_e + e];
-            cl_wait(flags, g, cluster, epoch, timeout);
-            // lottery-segment gather of my target rows
+            // publish dD_{t-1} of my slab
+            cl_ring_ready(done, g, cluster, lane, q - (CL_RING - 1), timeout);
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                const int rl = p * 64 + lane, a = r_lo + rl;
+                if (a < r_hi) st_gran(&xe[2 * (size_t)a], tag, dDsh[e * RP + rl]);
+            }
+            // lottery-segment gather of my target rows (per-lane re-read until the source row is current)
+            unsigned spins = 0;
+            bool dead = false;
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
                 const int rl = p * 64 + lane, r = r_lo + rl;
                 if (r < r_hi) {
                     double acc = 0.0;
-                    for (int j = s0[p]; j < s1[p]; j++)
-                        acc += lw[tb + j] * ld_sc1(&xe[j]) + dpn[tb + j] * gD[tb + j];
-                    for (int j = s1[p]; j < s2[p]; j++)
-                        acc += (1.0 - lw[tb + j]) * ld_sc1(&xe[j]) - dpn[tb + j] * gD[tb + j];
+                    for (int j = s0[p]; j < s2[p]; j++) {
+                        double v;
+                        while (!ld_gran(&xe[2 * (size_t)j], tag, v) && !dead) {
+                            dead = cl_timed_out(spins, timeout);
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        const double w = lw[tb + j], dwD = dpn[tb + j] * gD[tb + j];
+                        acc += (j < s1[p]) ? (w * v + dwD) : ((1.0 - w) * v - dwD);
+                    }
                     midsh[e * RP + rl] = acc;
                 }
             }
             if (member == 0 && clo > 0) {   // the mass point: sum_{j<clo} dD_{t-1}[j] -> row 0, by the column's wave
                 double s = 0.0;
-                for (int j = lane; j < clo; j += 64) s += ld_sc1(&xe[j]);
+                for (int j = lane; j < clo; j += 64) {
+                    double v;
+                    while (!ld_gran(&xe[2 * (size_t)j], tag, v) && !dead) {
+                        dead = cl_timed_out(spins, timeout);
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    s += v;
+                }
                 s = wave_sum(s);
                 if (lane == 0) midsh[e * RP] += s;
             }
@@ -367,8 +417,10 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
             for (int p = 0; p < NPASS; p++) {
                 const int rl = p * 64 + lane, r = r_lo + rl;
                 if (r < r_hi) {
-                    double dDn = midsh[rl] * Pi[n_e * e];      // dD_t[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
-                    for (int k = 1; k < n_e; k++) dDn += midsh[k * RP + rl] * Pi[k + n_e * e];
+                    double dDn = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (k < n_e) dDn += midsh[k * RP + rl] * pic[k];
                     dDsh[e * RP + rl] = dDn;
                     part += cp[p] * dDn + cdp[p] * cDn[p];
                 }
@@ -382,6 +434,8 @@ k_tanc_fwd(int n_a, int n_e, int G, int P, int N, ClGeom g, const double *__rest
                 double tot = 0.0;
                 for (int k = 0; k < n_e; k++) tot += red[k];
                 aggpart[((size_t)n * P + t) * g.CS + member] = tot;
+                if (g.CS > 1)   // all gathers of period q by this workgroup have completed (they fed midsh)
+                    __hip_atomic_store(&done[cluster * g.CS + member], (unsigned)(q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

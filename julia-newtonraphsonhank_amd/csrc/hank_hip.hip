@@ -23,8 +23,8 @@ struct TanWork {
     size_t lds_back = 0, lds_fwd = 0;
     double *dxhh = nullptr;   // (2,P,N) staging for the host-pointer entry
     double *dxr = nullptr, *dxw = nullptr;
-    double *xbuf = nullptr;     // [nclusters][2][G] exchange tiles (L2-resident)
-    unsigned *flags = nullptr;  // [2][nclusters*CS] epoch flags (backward, forward) + timeout word
+    u64_t *xbuf = nullptr;      // [nclusters][CL_RING][G][2] tagged-granule exchange ring
+    unsigned *flags = nullptr;  // [2][nclusters*CS] per-member `done` counters (backward, forward) + timeout word
     double *dpol = nullptr;     // [N][P][G]
     double *aggpart = nullptr;  // [N][P][CS]
     double *dagg = nullptr;     // [P][N]
@@ -93,31 +93,38 @@ static void free_tanwork(TanWork &w) {
 // ---- cluster sweep launches (dispatch over the compile-time passes per slab) ----------------------
 #define NPASS_CASES(X) X(1) X(2) X(4) X(8)
 
-static hipError_t launch_tanc_back(hank_ctx *ctx, TanWork &w, hipStream_t s) {
+template <int NP, int MAXT>
+static void launch_tanc_back_t(hank_ctx *ctx, TanWork &w, hipStream_t s) {
     const Consts &c = ctx->c;
     const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * (c.n_e + 1));
-    switch (w.npass) {
-#define X(NP) case NP: \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_back<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_back); \
-        hipLaunchKernelGGL(k_tanc_back<NP>, grid, blk, w.lds_back, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.a, c.z, c.Pi, \
-                           TAN_REC_ARGS(ctx->R, ctx->d_rho), w.dxr, w.dxw, w.xbuf, w.flags, w.flags + 2 * w.nflags, w.dpol, w.dbg); break;
-        NPASS_CASES(X)
-#undef X
-    }
-    return hipGetLastError();
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_back<NP, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_back);
+    hipLaunchKernelGGL((k_tanc_back<NP, MAXT>), grid, blk, w.lds_back, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.a, c.z, c.Pi,
+                       TAN_REC_ARGS(ctx->R, ctx->d_rho), w.dxr, w.dxw, w.xbuf, w.flags, w.flags + 2 * w.nflags, w.dpol, w.dbg);
 }
-static hipError_t launch_tanc_fwd(hank_ctx *ctx, TanWork &w, hipStream_t s) {
+template <int NP, int MAXT>
+static void launch_tanc_fwd_t(hank_ctx *ctx, TanWork &w, hipStream_t s) {
     const Consts &c = ctx->c;
     const Record &R = ctx->R;
     const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * (c.n_e + 1));
-    switch (w.npass) {
-#define X(NP) case NP: \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_fwd<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_fwd); \
-        hipLaunchKernelGGL(k_tanc_fwd<NP>, grid, blk, w.lds_fwd, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.Pi, R.lw, R.gD, R.Dseq, R.pol, \
-                           R.start, R.clo, w.xbuf, w.flags + w.nflags, w.flags + 2 * w.nflags, w.dpol, w.aggpart); break;
-        NPASS_CASES(X)
-#undef X
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_fwd<NP, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_fwd);
+    hipLaunchKernelGGL((k_tanc_fwd<NP, MAXT>), grid, blk, w.lds_fwd, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.Pi, R.lw, R.gD, R.Dseq, R.pol,
+                       R.start, R.clo, w.xbuf, w.flags + w.nflags, w.flags + 2 * w.nflags, w.dpol, w.aggpart);
+}
+// register budget follows the block size: <= 768 threads (n_e <= 11) leaves 168 VGPRs per lane
+#define TANC_DISPATCH(FN)                                                                       \
+    const bool small = 64 * (ctx->c.n_e + 1) <= 768;                                            \
+    switch (w.npass) {                                                                          \
+    case 1: small ? FN<1, 768>(ctx, w, s) : FN<1, 1024>(ctx, w, s); break;                      \
+    case 2: small ? FN<2, 768>(ctx, w, s) : FN<2, 1024>(ctx, w, s); break;                      \
+    case 4: small ? FN<4, 768>(ctx, w, s) : FN<4, 1024>(ctx, w, s); break;                      \
+    default: small ? FN<8, 768>(ctx, w, s) : FN<8, 1024>(ctx, w, s); break;                     \
     }
+static hipError_t launch_tanc_back(hank_ctx *ctx, TanWork &w, hipStream_t s) {
+    TANC_DISPATCH(launch_tanc_back_t)
+    return hipGetLastError();
+}
+static hipError_t launch_tanc_fwd(hank_ctx *ctx, TanWork &w, hipStream_t s) {
+    TANC_DISPATCH(launch_tanc_fwd_t)
     return hipGetLastError();
 }
 
@@ -191,7 +198,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     HIPC(ctx, dmalloc(&w.dxhh, 2 * P * N));
     HIPC(ctx, dmalloc(&w.dxr, P * N));
     HIPC(ctx, dmalloc(&w.dxw, P * N));
-    HIPC(ctx, dmalloc(&w.xbuf, (size_t)ncl * 2 * G));
+    HIPC(ctx, dmalloc(&w.xbuf, (size_t)ncl * CL_RING * G * 2));
     HIPC(ctx, dmalloc(&w.flags, (size_t)2 * w.nflags + 4));
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
     HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)cs * N));
@@ -207,6 +214,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     // backward tangent sweep: one persistent launch
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_zero_i32, dim3((nfl + 255) / 256), dim3(256), 0, s, (int *)w.flags, nfl);
+    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, (double *)w.xbuf, (size_t)ncl * CL_RING * G * 2);
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
     hipError_t le = launch_tanc_back(ctx, w, s);
     int rc = end_capture(ctx, &w.g_back);
@@ -214,6 +222,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     HIPC(ctx, le);
     // forward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, (double *)w.xbuf, (size_t)ncl * CL_RING * G * 2);
     le = launch_tanc_fwd(ctx, w, s);
     hipLaunchKernelGGL(k_tanc_sum, dim3((PN + 255) / 256), dim3(256), 0, s, w.aggpart, (int)P, N, cs, w.dagg);
     hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);

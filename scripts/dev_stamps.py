@@ -15,8 +15,8 @@ lib = hip.load_library()
 out = (C.c_ulonglong * (256 * 8))()
 lib.hank_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 n = lib.hank_debug_stamps(hb._ctx, out, 256)
-a = np.array(out[:n * 8], dtype=np.float64).reshape(n, 8) / 299.0 / 100.0   # s_memtime ticks at 100 MHz -> us per period
-names = ["loop top", "X compute+st", "publish(drain+bar+flag)", "coef loads issue", "wait(poll+bar)", "gather+Y", "end barrier"]
-print("per-period us (mean / min / max over workgroups):")
-for k, nm in enumerate(names): print(f"  {nm:28s} {a[:,k].mean():7.3f} {a[:,k].min():7.3f} {a[:,k].max():7.3f}")
+a = np.array(out[:n * 8], dtype=np.float64).reshape(n, 8) / 299.0   # shader cycles per period
+names = ["loop top", "coef issue + X compute", "ring check + granule stores", "barrier (X reads done)", "gather poll", "Y compute + dpol store", "end barrier + done flag"]
+print("per-period shader cycles (mean / min / max over workgroups):")
+for k, nm in enumerate(names): print(f"  {nm:28s} {a[:,k].mean():9.0f} {a[:,k].min():9.0f} {a[:,k].max():9.0f}")
 print("  sum", a[:, :7].sum(axis=1).mean(), hb.last_timings())
