@@ -4,7 +4,6 @@
 // Y half of period t, so the loop-carried state only crosses a launch boundary once per period,
 // and the 2(T-1) dependent launches are replayed from hipGraphs (no host launch cost).
 #include "hank_kernels.h"
-#include "hank_cluster.h"
 #include "../../include/hank_hip.h"
 
 #include <cstdarg>
@@ -18,19 +17,16 @@ using namespace hank;
 
 struct TanWork {
     int N = 0;
-    ClGeom g{};
-    int npass = 0;
-    size_t lds_back = 0, lds_fwd = 0;
+    TanGeom g{};
     double *dxhh = nullptr;   // (2,P,N) staging for the host-pointer entry
     double *dxr = nullptr, *dxw = nullptr;
-    u64_t *xbuf = nullptr;      // [nclusters][CL_RING][G][2] tagged-granule exchange ring
-    unsigned *flags = nullptr;  // [2][nclusters*CS] per-member `done` counters (backward, forward) + timeout word
-    double *dpol = nullptr;     // [N][P][G]
-    double *aggpart = nullptr;  // [N][P][CS]
+    double *ds[2] = {nullptr, nullptr};
+    double *dD[2] = {nullptr, nullptr};
+    double *dpol = nullptr;
+    double *aggpart = nullptr;
     double *dagg = nullptr;     // [P][N]
     double *dagg_cm = nullptr;  // (P,N) column-major
-    int nflags = 0;
-    unsigned long long *dbg = nullptr;  // per-workgroup phase stamps (diagnostic builds only)
+    int nbx = 0;
     hipGraphExec_t g_back = nullptr, g_fwd = nullptr;
     bool valid = false;  // dpol holds the partials of the current primal
 };
@@ -42,10 +38,9 @@ struct hank_ctx {
     int T = 0;
     double *d_a = nullptr, *d_z = nullptr, *d_Pi = nullptr;
     double *d_ss_value = nullptr, *d_ss_D = nullptr;  // d_ss_D aliases Dseq[0]
-    double *d_xhh = nullptr, *d_agg = nullptr, *d_aggpart = nullptr, *d_rho = nullptr;
+    double *d_xhh = nullptr, *d_agg = nullptr, *d_aggpart = nullptr;
     int *d_err = nullptr;
     int nbp = 0;  // row blocks of the primal kernels
-    int n_cu = 0;
     bool boundary_set = false, primal_done = false;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipGraphExec_t g_pback = nullptr, g_pfwd = nullptr;
@@ -85,47 +80,10 @@ static size_t primal_lds(const Consts &c) { return sizeof(double) * ((size_t)c.n
 static void free_tanwork(TanWork &w) {
     if (w.g_back) (void)hipGraphExecDestroy(w.g_back);
     if (w.g_fwd) (void)hipGraphExecDestroy(w.g_fwd);
-    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw); (void)hipFree(w.xbuf); (void)hipFree(w.flags); (void)hipFree(w.dbg);
+    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw);
+    (void)hipFree(w.ds[0]); (void)hipFree(w.ds[1]); (void)hipFree(w.dD[0]); (void)hipFree(w.dD[1]);
     (void)hipFree(w.dpol); (void)hipFree(w.aggpart); (void)hipFree(w.dagg); (void)hipFree(w.dagg_cm);
     w = TanWork();
-}
-
-// ---- cluster sweep launches (dispatch over the compile-time passes per slab) ----------------------
-#define NPASS_CASES(X) X(1) X(2) X(4) X(8)
-
-template <int NP, int MAXT>
-static void launch_tanc_back_t(hank_ctx *ctx, TanWork &w, hipStream_t s) {
-    const Consts &c = ctx->c;
-    const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * (c.n_e + 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_back<NP, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_back);
-    hipLaunchKernelGGL((k_tanc_back<NP, MAXT>), grid, blk, w.lds_back, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.a, c.z, c.Pi,
-                       TAN_REC_ARGS(ctx->R, ctx->d_rho), w.dxr, w.dxw, w.xbuf, w.flags, w.flags + 2 * w.nflags, w.dpol, w.dbg);
-}
-template <int NP, int MAXT>
-static void launch_tanc_fwd_t(hank_ctx *ctx, TanWork &w, hipStream_t s) {
-    const Consts &c = ctx->c;
-    const Record &R = ctx->R;
-    const dim3 grid(w.g.nclusters * w.g.CS), blk(64 * (c.n_e + 1));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tanc_fwd<NP, MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds_fwd);
-    hipLaunchKernelGGL((k_tanc_fwd<NP, MAXT>), grid, blk, w.lds_fwd, s, c.n_a, c.n_e, c.G, c.P, w.N, w.g, c.Pi, R.lw, R.gD, R.Dseq, R.pol,
-                       R.start, R.clo, w.xbuf, w.flags + w.nflags, w.flags + 2 * w.nflags, w.dpol, w.aggpart);
-}
-// register budget follows the block size: <= 768 threads (n_e <= 11) leaves 168 VGPRs per lane
-#define TANC_DISPATCH(FN)                                                                       \
-    const bool small = 64 * (ctx->c.n_e + 1) <= 768;                                            \
-    switch (w.npass) {                                                                          \
-    case 1: small ? FN<1, 768>(ctx, w, s) : FN<1, 1024>(ctx, w, s); break;                      \
-    case 2: small ? FN<2, 768>(ctx, w, s) : FN<2, 1024>(ctx, w, s); break;                      \
-    case 4: small ? FN<4, 768>(ctx, w, s) : FN<4, 1024>(ctx, w, s); break;                      \
-    default: small ? FN<8, 768>(ctx, w, s) : FN<8, 1024>(ctx, w, s); break;                     \
-    }
-static hipError_t launch_tanc_back(hank_ctx *ctx, TanWork &w, hipStream_t s) {
-    TANC_DISPATCH(launch_tanc_back_t)
-    return hipGetLastError();
-}
-static hipError_t launch_tanc_fwd(hank_ctx *ctx, TanWork &w, hipStream_t s) {
-    TANC_DISPATCH(launch_tanc_fwd_t)
-    return hipGetLastError();
 }
 
 // ---- graph construction -----------------------------------------------------------------------
@@ -147,7 +105,6 @@ static int build_primal_graphs(hank_ctx *ctx) {
     // backward: X of the last period from the terminal value, then P fused Y;X steps, then lottery
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
-    hipLaunchKernelGGL(k_rho, dim3((P + 255) / 256), dim3(256), 0, s, ctx->d_xhh, P, ctx->d_rho);
     hipLaunchKernelGGL(k_egm_X, grd, blk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
                        ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1);
     for (int t = P - 1; t >= 0; t--)
@@ -161,7 +118,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
         hipLaunchKernelGGL(k_dist_step, grd, blk, lds, s, c, ctx->R, t, ctx->d_aggpart);
     hipLaunchKernelGGL(k_reduce_parts, dim3(P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
     rc = end_capture(ctx, &ctx->g_pfwd);
-    ctx->launches[0] = P + 4;
+    ctx->launches[0] = P + 2;
     ctx->launches[1] = P + 1;
     return rc;
 }
@@ -173,64 +130,54 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     const Consts &c = ctx->c;
     const size_t P = c.P, G = c.G;
     w.N = N;
-    // cluster geometry: CS workgroups (one per CU) share one tangent direction; as many clusters as
-    // the chip holds, a cluster loops over its share of the N directions.
-    int cs_min = 1;
-    while ((c.n_a + cs_min - 1) / cs_min > CL_MAXPASS * 64) cs_min <<= 1;
-    int cs = 8;
-    while (cs > 1 && (ctx->n_cu / cs) < N && cs > cs_min) cs >>= 1;   // more directions than clusters: shrink clusters
-    if (cs < cs_min) cs = cs_min;
-    if (cs > ctx->n_cu) return fail(ctx, HANK_ERR_BAD_ARG, "wealth grid too large for the cluster sweep (n_a=%d)", c.n_a);
-    int ncl = ctx->n_cu / cs;
-    if (ncl > N) ncl = N;
-    if (ncl >= 8) ncl -= ncl % 8;
-    w.g.CS = cs; w.g.nclusters = ncl; w.g.RM = (c.n_a + cs - 1) / cs; w.g.xcd_map = (ncl % 8 == 0) ? 1 : 0;
-    int np = (w.g.RM + 63) / 64;
-    w.npass = np <= 1 ? 1 : (np <= 2 ? 2 : (np <= 4 ? 4 : 8));
-    const size_t RP = (size_t)w.npass * 64;
-    // >= 84 KiB of LDS per workgroup: exactly one workgroup per CU (hand-off form requires it)
-    const size_t min_lds = 84 * 1024;
-    w.lds_back = sizeof(double) * c.n_e * RP + 256;
-    w.lds_fwd = sizeof(double) * (2 * c.n_e * RP + 16) + 256;
-    if (w.lds_back < min_lds) w.lds_back = min_lds;
-    if (w.lds_fwd < min_lds) w.lds_fwd = min_lds;
-    w.nflags = ncl * cs;
+    int NC = 1, lg = 0;
+    while (NC < N && NC < 64) { NC <<= 1; lg++; }
+    const int RB = 64 / NC;
+    w.nbx = (c.n_a + RB - 1) / RB;
+    w.g.N = N; w.g.NC = NC; w.g.lgNC = lg; w.g.nbx = w.nbx;
+    const size_t GV = (size_t)(c.n_a + KV) * c.n_e;   // dD state carries KV virtual rows per column
     HIPC(ctx, dmalloc(&w.dxhh, 2 * P * N));
     HIPC(ctx, dmalloc(&w.dxr, P * N));
     HIPC(ctx, dmalloc(&w.dxw, P * N));
-    HIPC(ctx, dmalloc(&w.xbuf, (size_t)ncl * CL_RING * G * 2));
-    HIPC(ctx, dmalloc(&w.flags, (size_t)2 * w.nflags + 4));
+    for (int k = 0; k < 2; k++) {
+        HIPC(ctx, dmalloc(&w.ds[k], G * N));
+        HIPC(ctx, dmalloc(&w.dD[k], GV * N));
+    }
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)cs * N));
+    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)(w.nbx + KV) * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
-#ifdef HANK_STAMPS
-    HIPC(ctx, dmalloc(&w.dbg, (size_t)ncl * cs * 8));
-#endif
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
 
     hipStream_t s = ctx->own_stream;
+    const dim3 blk(64 * c.n_e);
+    const unsigned ny = (N + NC - 1) / NC;
     const int PN = (int)(P * N);
-    const int nfl = 2 * w.nflags + 4;
-    // backward tangent sweep: one persistent launch
+    // backward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(k_zero_i32, dim3((nfl + 255) / 256), dim3(256), 0, s, (int *)w.flags, nfl);
-    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, (double *)w.xbuf, (size_t)ncl * CL_RING * G * 2);
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    hipError_t le = launch_tanc_back(ctx, w, s);
+    hipLaunchKernelGGL(k_tan_back, dim3(w.nbx, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, (int)P - 1, 1,
+                       w.ds[1], w.ds[0], w.dpol);
+    int cur = 0;
+    for (int t = (int)P - 1; t >= 0; t--) {
+        hipLaunchKernelGGL(k_tan_back, dim3(w.nbx, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, t, 0,
+                           w.ds[cur], w.ds[cur ^ 1], w.dpol);
+        cur ^= 1;
+    }
     int rc = end_capture(ctx, &w.g_back);
     if (rc) return rc;
-    HIPC(ctx, le);
     // forward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, (double *)w.xbuf, (size_t)ncl * CL_RING * G * 2);
-    le = launch_tanc_fwd(ctx, w, s);
-    hipLaunchKernelGGL(k_tanc_sum, dim3((PN + 255) / 256), dim3(256), 0, s, w.aggpart, (int)P, N, cs, w.dagg);
+    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
+    cur = 0;
+    for (int t = 0; t < (int)P; t++) {
+        hipLaunchKernelGGL(k_tan_fwd, dim3(w.nbx + KV, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, w.nbx + KV, N, w.dagg);
     hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
     rc = end_capture(ctx, &w.g_fwd);
-    if (rc) return rc;
-    HIPC(ctx, le);
-    ctx->launches[2] = 1;
-    ctx->launches[3] = 1;
+    ctx->launches[2] = (int)P + 2;
+    ctx->launches[3] = (int)P + 3;
     return rc;
 }
 
@@ -258,8 +205,6 @@ static int fetch_device_error(hank_ctx *ctx) {
     }
 }
 
-static int check_tangent_timeout(hank_ctx *ctx);
-
 // ================================ C ABI =========================================================
 extern "C" {
 
@@ -274,8 +219,8 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     hank_ctx *ctx = new (std::nothrow) hank_ctx();
     if (!ctx) return HANK_ERR_NOMEM;
     *out = ctx;  // returned even on failure so the caller can read hank_last_error, then destroy
-    if (m->n_a < 2 || m->n_e < 1 || m->n_e > 15 || m->T < 2)
-        return fail(ctx, HANK_ERR_BAD_ARG, "bad shape: n_a=%d (>=2), n_e=%d (1..15), T=%d (>=2)", m->n_a, m->n_e, m->T);
+    if (m->n_a < 2 || m->n_e < 1 || m->n_e > 16 || m->T < 2)
+        return fail(ctx, HANK_ERR_BAD_ARG, "bad shape: n_a=%d (>=2), n_e=%d (1..16), T=%d (>=2)", m->n_a, m->n_e, m->T);
     if (m->value_fn_id != HANK_VF_KRUSELL_SMITH)
         return fail(ctx, HANK_ERR_BAD_ARG, "unknown value function id %d", m->value_fn_id);
     if (!m->a_grid || !m->z_grid || !m->Pi) return fail(ctx, HANK_ERR_BAD_ARG, "null grid pointer");
@@ -284,7 +229,6 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, hipGetDevice(&ctx->device));
     hipDeviceProp_t prop;
     HIPC(ctx, hipGetDeviceProperties(&prop, ctx->device));
-    ctx->n_cu = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(ctx, HANK_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", ctx->device, prop.gcnArchName);
     Consts &c = ctx->c;
@@ -308,7 +252,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, dmalloc(&R.A, P * G)); HIPC(ctx, dmalloc(&R.B, P * G));
     HIPC(ctx, dmalloc(&R.u, P * G)); HIPC(ctx, dmalloc(&R.v, P * G));
     HIPC(ctx, dmalloc(&R.pol, P * G)); HIPC(ctx, dmalloc(&R.lw, P * G));
-    HIPC(ctx, dmalloc(&R.ig, P * G)); HIPC(ctx, dmalloc(&R.gD, P * G)); HIPC(ctx, dmalloc(&R.Dseq, (P + 1) * G));
+    HIPC(ctx, dmalloc(&R.ig, P * G)); HIPC(ctx, dmalloc(&R.Dseq, (P + 1) * G));
     HIPC(ctx, dmalloc(&R.ib, P * G)); HIPC(ctx, dmalloc(&R.lo, P * G));
     HIPC(ctx, dmalloc(&R.start, P * (size_t)c.n_e * (c.n_a + 1)));
     HIPC(ctx, dmalloc(&R.clo, P * (size_t)c.n_e));
@@ -317,7 +261,6 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     ctx->nbp = (c.n_a + RBP - 1) / RBP;
     HIPC(ctx, dmalloc(&ctx->d_xhh, 2 * P));
     HIPC(ctx, dmalloc(&ctx->d_agg, P));
-    HIPC(ctx, dmalloc(&ctx->d_rho, P));
     HIPC(ctx, dmalloc(&ctx->d_aggpart, P * (size_t)ctx->nbp));
     HIPC(ctx, dmalloc(&ctx->d_err, 4));
     HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
@@ -335,9 +278,9 @@ int hank_destroy(hank_ctx *ctx) {
     if (ctx->g_pfwd) (void)hipGraphExecDestroy(ctx->g_pfwd);
     Record &R = ctx->R;
     (void)hipFree(R.s); (void)hipFree(R.kc); (void)hipFree(R.A); (void)hipFree(R.B); (void)hipFree(R.u); (void)hipFree(R.v);
-    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.gD); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo);
+    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
-    (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_rho); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
+    (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 8; k++)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -395,9 +338,7 @@ int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
 
 int hank_check(hank_ctx *ctx) {
     if (!ctx) return HANK_ERR_BAD_ARG;
-    int rc = fetch_device_error(ctx);
-    if (rc) return rc;
-    return ctx->tw.flags ? check_tangent_timeout(ctx) : HANK_OK;
+    return fetch_device_error(ctx);
 }
 
 int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
@@ -416,18 +357,6 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
         HIPC(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->errmsg[0] = 0;
-    return HANK_OK;
-}
-
-static int check_tangent_timeout(hank_ctx *ctx) {
-    unsigned tmo = 0;
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    HIPC(ctx, hipMemcpy(&tmo, ctx->tw.flags + 2 * ctx->tw.nflags, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (tmo) {
-        ctx->tw.valid = false;
-        return fail(ctx, HANK_ERR_NO_DEVICE, "internal error: a cluster hand-off of the tangent sweep timed out "
-                                              "(workgroups of a cluster were not co-resident)");
-    }
     return HANK_OK;
 }
 
@@ -467,8 +396,6 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
     if (rc) return rc;
     HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    rc = check_tangent_timeout(ctx);
-    if (rc) return rc;
     ctx->errmsg[0] = 0;
     return HANK_OK;
 }
@@ -509,10 +436,15 @@ int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
     TanWork &w = ctx->tw;
     if (!w.valid || w.N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
-    // device layout [n][t][e][a] IS the column-major (G, P, N) array
     const size_t total = (size_t)ctx->c.P * ctx->c.G * N;
-    HIPC(ctx, hipMemcpyAsync(out, w.dpol, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    double *tmp = nullptr;
+    HIPC(ctx, dmalloc(&tmp, total));
+    hipLaunchKernelGGL(k_export_dpol, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w.dpol, ctx->c.G, ctx->c.P, N, tmp);
+    hipError_t e1 = hipMemcpyAsync(out, tmp, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    HIPC(ctx, e1);
+    HIPC(ctx, e2);
     return HANK_OK;
 }
 
@@ -636,14 +568,3 @@ int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dp
 }
 
 }  // extern "C"
-
-#ifdef HANK_STAMPS
-extern "C" int hank_debug_stamps(hank_ctx *ctx, unsigned long long *out, int max_wg) {
-    TanWork &w = ctx->tw;
-    int n = w.g.nclusters * w.g.CS;
-    if (n > max_wg) n = max_wg;
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipMemcpy(out, w.dbg, sizeof(unsigned long long) * n * 8, hipMemcpyDeviceToHost);
-    return n;
-}
-#endif

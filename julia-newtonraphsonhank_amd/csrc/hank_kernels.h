@@ -28,7 +28,7 @@ struct Consts {
 };
 
 struct Record {
-    double *s, *kc, *A, *B, *u, *v, *pol, *lw, *ig, *gD, *Dseq;
+    double *s, *kc, *A, *B, *u, *v, *pol, *lw, *ig, *Dseq;
     int *ib, *lo, *start, *clo;
 };
 
@@ -261,7 +261,6 @@ __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
     const double *lw = R.lw + base + (size_t)e * n, *Dp = Dprev + (size_t)e * n;
     double acc = 0.0;
     if (r < n) {
-        R.gD[base + (size_t)e * n + r] = R.ig[base + (size_t)e * n + r] * Dp[r];   // weight-tangent factor of source row r
         const int *st = R.start + ((size_t)t * c.n_e + e) * (n + 1);
         const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
         for (int j = st0; j < st1; j++) acc += lw[j] * Dp[j];
@@ -340,206 +339,132 @@ __global__ void k_tan_out(const double *__restrict__ dagg, int P, int N, double 
     out[idx] = dagg[(size_t)t * N + n];
 }
 
-// read-only views of the primal record for the tangent kernels: separate __restrict__ kernel
-// arguments so that wave-uniform coefficient reads become scalar (SMEM) loads.
-#define TAN_REC_PARAMS                                                                          \
-    const int *__restrict__ ib, const double *__restrict__ rA, const double *__restrict__ rB,   \
-    const double *__restrict__ ru, const double *__restrict__ rv, const double *__restrict__ rkc, \
-    const double *__restrict__ rs, const double *__restrict__ rho
-#define TAN_REC_ARGS(R, rho) (R).ib, (R).A, (R).B, (R).u, (R).v, (R).kc, (R).s, rho
-
-// rho[t] = 1/(1+r_t)
-__global__ void k_rho(const double *__restrict__ xhh, int P, double *__restrict__ rho) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < P) rho[t] = 1.0 / (1.0 + xhh[2 * t]);
-}
-
 // one backward period: Y-tangent of period t (bracket gather -> dpol_t, dV_t), then X-tangent of
 // period t-1 (mix over e -> knot tangents ds_{t-1}). `first`: dV_{t+1} = 0 for the last period
 // (terminal value has zero partials, BackwardIteration.jl:85) => only the X half, from zeros.
 // ds ping-pongs between two [e][a][N] buffers that live in L2 / Infinity Cache.
-// LGNC = log2(tangents per wave row). For NC >= 32 a wave covers <= 2 wealth rows: all per-point
-// coefficients are wave-uniform pairs -> scalar loads + a per-half select; only the state moves
-// through the vector memory path.
-template <int LGNC>
 __global__ void __launch_bounds__(1024)
-k_tan_back(int n_a, int n_e, int G, int N, int t, int first, const double *__restrict__ agrid,
-           const double *__restrict__ zg, const double *__restrict__ Pi, TAN_REC_PARAMS,
-           const double *__restrict__ dxr, const double *__restrict__ dxw,
-           const double *__restrict__ dsIn, double *__restrict__ dsOut, double *__restrict__ dpol) {
-    constexpr int NC = 1 << LGNC, RB = 64 >> LGNC;
-    constexpr bool SC = RB <= 2;
+k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__restrict__ dxr,
+           const double *__restrict__ dxw, TanGeom g, int t, int first, const double *__restrict__ dsIn,
+           double *__restrict__ dsOut, double *__restrict__ dpol) {
     __shared__ double dVsh[16 * 64];
-    const int lane = threadIdx.x & 63;
-    const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nl = lane & (NC - 1), rl = lane >> LGNC;
-    const int a0 = blockIdx.x * RB;
-    const int a = a0 + rl, n = blockIdx.y * NC + nl;
-    const bool valid = (a < n_a) && (n < N);
-    const size_t Ns = N;
-    const size_t pt = (size_t)e * n_a + a;
-    const int a1 = (a0 + 1 < n_a) ? a0 + 1 : a0;            // second row of the wave (SC path)
-    const size_t p0 = (size_t)e * n_a + a0, p1 = (size_t)e * n_a + a1;
-    const double ze = zg[e];
+    __shared__ double Pish[256];
+    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
+    const int a = blockIdx.x * (64 >> g.lgNC) + rl, n = blockIdx.y * g.NC + nl;
+    const bool valid = (a < c.n_a) && (n < g.N);
+    const size_t N = g.N;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    const size_t pt = (size_t)e * c.n_a + a;
     double dV = 0.0;
     if (valid && !first) {
-        const size_t tb = (size_t)t * G;
-        int i;
-        double cA, cB, cu, cv, xa;
-        if constexpr (SC) {
-            const int i0 = ib[tb + p0], i1 = ib[tb + p1];
-            const double A0 = rA[tb + p0], A1 = rA[tb + p1], B0 = rB[tb + p0], B1 = rB[tb + p1];
-            const double u0 = ru[tb + p0], u1 = ru[tb + p1], v0 = rv[tb + p0], v1 = rv[tb + p1];
-            const double x0 = agrid[a0], x1 = agrid[a1];
-            const bool hi = (RB == 2) && rl;
-            i = hi ? i1 : i0; cA = hi ? A1 : A0; cB = hi ? B1 : B0; cu = hi ? u1 : u0; cv = hi ? v1 : v0;
-            xa = hi ? x1 : x0;
-        } else {
-            const size_t off = tb + pt;
-            i = ib[off]; cA = rA[off]; cB = rB[off]; cu = ru[off]; cv = rv[off]; xa = agrid[a];
-        }
-        const double *col = dsIn + ((size_t)e * n_a) * Ns + n;
-        const double ds0 = col[(size_t)i * Ns], ds1 = col[(size_t)(i + 1) * Ns];
-        const double dr = dxr[(size_t)t * Ns + n], dw = dxw[(size_t)t * Ns + n];
-        const double dg = cA * ds0 + cB * ds1;
-        dpol[(tb + pt) * Ns + n] = dg;
-        dV = cu * dr + cv * ((xa * dr + ze * dw) - dg);
+        const size_t off = (size_t)t * c.G + pt;
+        const int i = R.ib[off];
+        const double *col = dsIn + ((size_t)e * c.n_a) * N + n;
+        const double ds0 = col[(size_t)i * N], ds1 = col[(size_t)(i + 1) * N];
+        const double dr = dxr[(size_t)t * N + n], dw = dxw[(size_t)t * N + n];
+        const double dg = R.A[off] * ds0 + R.B[off] * ds1;
+        dpol[off * N + n] = dg;
+        dV = R.u[off] * dr + R.v[off] * ((c.a[a] * dr + c.z[e] * dw) - dg);
     }
-    dVsh[(threadIdx.x >> 6) * 64 + lane] = dV;
+    dVsh[e * 64 + lane] = dV;
     __syncthreads();
     const int tx = first ? t : t - 1;   // period whose knots are produced
     if (valid && tx >= 0) {
-        double dE = dVsh[lane] * Pi[e];
-        for (int e2 = 1; e2 < n_e; e2++) dE += dVsh[e2 * 64 + lane] * Pi[e + n_e * e2];
-        const size_t tb1 = (size_t)tx * G;
-        double ckc, cs;
-        if constexpr (SC) {
-            const double k0 = rkc[tb1 + p0], k1 = rkc[tb1 + p1], s0 = rs[tb1 + p0], s1 = rs[tb1 + p1];
-            const bool hi = (RB == 2) && rl;
-            ckc = hi ? k1 : k0; cs = hi ? s1 : s0;
-        } else {
-            ckc = rkc[tb1 + pt]; cs = rs[tb1 + pt];
-        }
-        const double dr1 = dxr[(size_t)tx * Ns + n], dw1 = dxw[(size_t)tx * Ns + n];
-        dsOut[pt * Ns + n] = ckc * dE - rho[tx] * (ze * dw1 + cs * dr1);
+        double dE = dVsh[lane] * Pish[e];
+        for (int e2 = 1; e2 < c.n_e; e2++) dE += dVsh[e2 * 64 + lane] * Pish[e + c.n_e * e2];
+        const size_t off1 = (size_t)tx * c.G + pt;
+        const double rho1 = 1.0 / (1.0 + xhh[2 * tx]);
+        const double dr1 = dxr[(size_t)tx * N + n], dw1 = dxw[(size_t)tx * N + n];
+        dsOut[pt * N + n] = R.kc[off1] * dE - rho1 * (c.z[e] * dw1 + R.s[off1] * dr1);
     }
 }
 
 // one forward period: segment gather of the lottery tangent (ForwardIteration.jl:37-99 under
 // Dual), mix over e, aggregate dagg_t = sum(dpol_t * D_t + pol_t * dD_t) with the POST-transition
 // D_t (:301-307). dD state: [e][n_a + KV][N].
-//   blocks [0, nbx):      regular target rows; sources j >= clo only. For NC >= 32 the wave's <= 2
-//     target rows share ONE wave-uniform loop over the union of their source segments: lottery
-//     coefficients come through scalar loads, each source row is fetched once per wave.
+//   blocks [0, nbx):      regular target rows; sources j >= clo only.
 //   blocks [nbx, nbx+KV): the mass point. Block p sums its share of the clamped prefix [0, clo_e)
 //     of every column (weight one, no weight tangent) plus, when row 0 itself is clamped, its share
 //     of last period's virtual rows; after the mix the result is stored as VIRTUAL ROW n_a+p: row
 //     0's tangent is (real row 0) + sum_p (virtual row p). Everything downstream is linear, so the
 //     parts are never combined: a virtual row is a source with row 0's lottery (no own policy
 //     tangent), and its aggregate term uses pol[0, e].
-template <int LGNC>
 __global__ void __launch_bounds__(1024)
-k_tan_fwd(int n_a, int n_e, int G, int N, int nbx, int t, const double *__restrict__ Pi,
-          const double *__restrict__ lw, const double *__restrict__ ig, const double *__restrict__ Dseq,
-          const double *__restrict__ pol, const int *__restrict__ start, const int *__restrict__ clo_,
-          const double *__restrict__ dDin, double *__restrict__ dDout, const double *__restrict__ dpol,
-          double *__restrict__ aggpart) {
-    constexpr int NC = 1 << LGNC, RB = 64 >> LGNC;
-    constexpr bool SC = RB <= 2;
+k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin, double *__restrict__ dDout,
+          const double *__restrict__ dpol, double *__restrict__ aggpart) {
     __shared__ double sh[16 * 64];
-    const int lane = threadIdx.x & 63;
-    const int e = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nl = lane & (NC - 1), rl = lane >> LGNC;
-    const int n = blockIdx.y * NC + nl;
-    const size_t Ns = N;
-    const int na = n_a, nav = n_a + KV;
-    const size_t base = (size_t)t * G, cb = base + (size_t)e * na;
-    const double *Dprev = Dseq + base + (size_t)e * na, *Dnew = Dseq + base + G + (size_t)e * na;
-    const double *dDc = dDin + ((size_t)e * nav) * Ns + n;
-    const double *dpc = dpol + cb * Ns + n;
-    const int *st = start + ((size_t)t * n_e + e) * (na + 1);
-    const int clo = clo_[(size_t)t * n_e + e];
-    const bool virt_block = (int)blockIdx.x >= nbx;
-    const bool nok = n < N;
+    __shared__ double Pish[256];
+    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
+    const int RB = 64 >> g.lgNC;
+    const int n = blockIdx.y * g.NC + nl;
+    const size_t N = g.N;
+    const int na = c.n_a, nav = c.n_a + KV;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    const size_t base = (size_t)t * c.G, cb = base + (size_t)e * na;
+    const double *Dprev = R.Dseq + base + (size_t)e * na, *Dnew = R.Dseq + base + c.G;
+    const double *dDc = dDin + ((size_t)e * nav) * N + n;
+    const double *dpc = dpol + cb * N + n;
+    const int *st = R.start + ((size_t)t * c.n_e + e) * (na + 1);
+    const int clo = R.clo[(size_t)t * c.n_e + e];
+    const bool virt_block = (int)blockIdx.x >= g.nbx;
+    const bool nok = n < g.N;
     int r;          // row of the dD state this thread produces
     bool valid;
     double acc = 0.0;
     if (!virt_block) {
-        const int r0 = blockIdx.x * RB;
-        r = r0 + rl;
+        r = blockIdx.x * RB + rl;
         valid = (r < na) && nok;
-        if constexpr (SC) {
-            const int sB = st[r0], sC = st[r0 + 1], sA = r0 > 0 ? st[r0 - 1] : sB;
-            const int sD = (RB == 2 && r0 + 1 < na) ? st[r0 + 2] : sC;
-            const bool hi = (RB == 2) && rl;
-            if (nok) {
-                for (int j = sA; j < sD; j++) {     // wave-uniform: union of the rows' source segments
-                    const double w = lw[cb + j], gD = ig[cb + j] * Dprev[j];
-                    const double dDj = dDc[(size_t)j * Ns], dpj = dpc[(size_t)j * Ns];
-                    const double wt0 = j < sB ? w : (j < sC ? 1.0 - w : 0.0), sg0 = j < sB ? gD : (j < sC ? -gD : 0.0);
-                    const double wt1 = j < sB ? 0.0 : (j < sC ? w : 1.0 - w), sg1 = j < sB ? 0.0 : (j < sC ? gD : -gD);
-                    acc += (hi ? wt1 : wt0) * dDj + (hi ? sg1 : sg0) * dpj;
-                }
-            }
-        } else if (valid) {
+        if (valid) {
             const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
             for (int j = st0; j < st1; j++)
-                acc += lw[cb + j] * dDc[(size_t)j * Ns] + (dpc[(size_t)j * Ns] * ig[cb + j]) * Dprev[j];
+                acc += R.lw[cb + j] * dDc[(size_t)j * N] + (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
             for (int j = st1; j < st2; j++)
-                acc += (1.0 - lw[cb + j]) * dDc[(size_t)j * Ns] - (dpc[(size_t)j * Ns] * ig[cb + j]) * Dprev[j];
-        }
-        if (valid && clo == 0) {
-            // row 0 is not clamped: its virtual rows follow row 0's (interior) lottery
-            const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
-            if (st2 > 0 && (st0 == 0 || st1 == 0)) {
-                const double w0 = (st0 == 0 && st1 > 0) ? lw[cb] : 1.0 - lw[cb];
-                double vs = 0.0;
-                for (int k = 0; k < KV; k++) vs += dDc[(size_t)(na + k) * Ns];
-                acc += w0 * vs;
+                acc += (1.0 - R.lw[cb + j]) * dDc[(size_t)j * N] - (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
+            // row 0 not clamped: its virtual rows follow row 0's (interior) lottery
+            if (clo == 0 && st2 > 0 && (st0 == 0 || st1 == 0)) {
+                const double w0 = (st0 == 0 && st1 > 0) ? R.lw[cb] : 1.0 - R.lw[cb];
+                double v = 0.0;
+                for (int k = 0; k < KV; k++) v += dDc[(size_t)(na + k) * N];
+                acc += w0 * v;
             }
         }
     } else {
-        const int p = blockIdx.x - nbx;
+        const int p = blockIdx.x - g.nbx;
         r = na + p;
         valid = nok && (rl == 0);
         if (nok && clo > 0) {
             const int M = clo + KV;                         // clamped sources, then the virtual rows
             const int lo = (int)(((long long)M * p) / KV), hi = (int)(((long long)M * (p + 1)) / KV);
             for (int i = lo + rl; i < hi; i += RB)
-                acc += dDc[(size_t)(i < clo ? i : na + (i - clo)) * Ns];
+                acc += dDc[(size_t)(i < clo ? i : na + (i - clo)) * N];
         }
-        for (int off = 32; off >= NC; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        for (int off = 32; off >= g.NC; off >>= 1) acc += __shfl_xor(acc, off, 64);
     }
-    sh[(threadIdx.x >> 6) * 64 + lane] = acc;
+    sh[e * 64 + lane] = acc;
     __syncthreads();
     double part = 0.0;
     if (valid) {
-        double dDn = sh[lane] * Pi[n_e * e];              // dD_new[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
-        for (int k = 1; k < n_e; k++) dDn += sh[k * 64 + lane] * Pi[k + n_e * e];
-        dDout[((size_t)e * nav + r) * Ns + n] = dDn;
+        const int e2 = e;
+        double dDn = sh[lane] * Pish[c.n_e * e2];
+        for (int k = 1; k < c.n_e; k++) dDn += sh[k * 64 + lane] * Pish[k + c.n_e * e2];
+        dDout[((size_t)e2 * nav + r) * N + n] = dDn;
         if (!virt_block) {
-            double cp, cD;
-            if constexpr (SC) {
-                const int r0 = blockIdx.x * RB, r1 = (r0 + 1 < na) ? r0 + 1 : r0;
-                const double q0 = pol[cb + r0], q1 = pol[cb + r1], D0 = Dnew[r0], D1 = Dnew[r1];
-                const bool hi = (RB == 2) && rl;
-                cp = hi ? q1 : q0; cD = hi ? D1 : D0;
-            } else {
-                cp = pol[cb + r]; cD = Dnew[r];
-            }
-            part = cp * dDn + dpc[(size_t)r * Ns] * cD;
+            const size_t off = base + (size_t)e2 * na + r;
+            part = R.pol[off] * dDn + dpol[off * N + n] * Dnew[(size_t)e2 * na + r];
         } else {
-            part = pol[cb] * dDn;
+            part = R.pol[base + (size_t)e2 * na] * dDn;
         }
     }
     __syncthreads();
-    sh[(threadIdx.x >> 6) * 64 + lane] = part;
+    sh[e * 64 + lane] = part;
     __syncthreads();
-    if (threadIdx.x < 64) {   // sum over columns, then over the RB row lanes of each tangent
+    if (e == 0) {   // sum over columns, then over the RB row lanes of each tangent
         double s = sh[lane];
-        for (int k = 1; k < n_e; k++) s += sh[k * 64 + lane];
-        for (int off = 32; off >= NC; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (rl == 0 && nok) aggpart[((size_t)t * gridDim.x + blockIdx.x) * Ns + n] = s;
+        for (int k = 1; k < c.n_e; k++) s += sh[k * 64 + lane];
+        for (int off = 32; off >= g.NC; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (rl == 0 && nok) aggpart[((size_t)t * gridDim.x + blockIdx.x) * N + n] = s;
     }
 }
 
