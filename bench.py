@@ -170,13 +170,16 @@ def main():
         bytes_per_launch = G * 8 * N
         avg_launch_s = 1e-3 * acc[dom] / launches[dom]
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        pmc = None
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE in separate runs, profiles/r01b_pmc_*): a profile artefact, not measured live
+        pmc, traffic = None, None
         pmc_file = ROOT / "profiles" / "pmc_latest.json"
-        if pmc_file.exists():
+        if pmc_file.exists() and N == WORKLOADS[args.workload]["N"]:
             try:
                 pmc = json.loads(pmc_file.read_text()).get(args.workload, {}).get(kname)
+                traffic = pmc["hbm_bytes"] if pmc else None
             except Exception:
-                pmc = None
+                pmc, traffic = None, None
         b_alg_batch = 2 * P * G * 8 * (1 + N)
         out = {
             "metric": "sequence-space JVPs/sec (household block: BackwardIteration+ForwardIteration+aggregation, Krusell-Smith T=300)",
@@ -187,7 +190,7 @@ def main():
                        "step": "1 primal sweep + 1 batched JVP of N tangents" + (" + RCCL all-gather" if world > 1 else ""),
                        "parallelism": f"tangent-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": pmc,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_launch_s,
                          "note": "avg launch = HIP-event time of the whole sweep / launches (includes the dependent-launch gaps)"},
             "whole_batch": {"B_alg_bytes": b_alg_batch, "achieved_GBs": b_alg_batch / (1e-3 * ms_per_step) / 1e9,

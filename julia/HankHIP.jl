@@ -1,0 +1,125 @@
+# HankHIP.jl — the reference-side binding a maintainer of vasudeva-ram/Julia-NewtonRaphsonHANK would add:
+# the SAME Julia signatures as BackwardIteration.jl / ForwardIteration.jl, bodies replaced by `ccall`s
+# into libhank_hip.so (include/hank_hip.h). `include` it AFTER the reference's own files; NewtonRaphson.jl,
+# ModelParser.jl, SteadyState.jl and the YAML stay untouched.
+#
+# NOT EXERCISED IN THIS REPOSITORY'S CI: no Julia toolchain exists in the build image (SURVEY.md §8c).
+# The C ABI it binds is exercised through the Python ctypes binding (julia-newtonraphsonhank_amd/hip.py),
+# which makes exactly the same calls.
+#
+#   policy_seqs = BackwardIteration(x, exog_paths, mod, ss_end)          # BackwardIteration.jl:46-49
+#   agg_seqs    = ForwardIteration(policy_seqs, mod, ss_initial)         # ForwardIteration.jl:253-255
+#
+# With x::Vector{Float64} both run the fused Float64 sweep (hank_primal); with
+# x::Vector{ForwardDiff.Dual{T,Float64,N}} the N partials travel as one tangent batch (hank_jvp), so
+# `JVP(fullFunction, x, y)` (GeneralStructures.jl:542-550) and ForwardDiff.jacobian chunks work unchanged.
+
+using ForwardDiff: Dual, value, partials
+
+const LIBHANK = get(ENV, "HANK_HIP_LIB", joinpath(@__DIR__, "..", "julia-newtonraphsonhank_amd", "libhank_hip.so"))
+
+struct HankModelC            # mirrors `hank_model` in include/hank_hip.h
+    n_a::Int32; n_e::Int32; T::Int32; value_fn_id::Int32
+    a_grid::Ptr{Float64}; z_grid::Ptr{Float64}; Pi::Ptr{Float64}
+    beta::Float64; gamma::Float64; borrow_cons::Float64
+end
+
+mutable struct HankCtx
+    ptr::Ptr{Cvoid}
+    P::Int; G::Int; n_a::Int; n_e::Int
+end
+
+const _CTX = IdDict{Any,HankCtx}()     # one device context per SequenceModel
+
+function _check(ctx::Ptr{Cvoid}, rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:hank_last_error, LIBHANK), Cstring, (Ptr{Cvoid},), ctx))
+    error(msg)      # the library's messages restate the reference's own exceptions (knots / DomainError)
+end
+
+function hank_context(model::SequenceModel)
+    get!(_CTX, model) do
+        w = model.heterogeneity.wealth; p = model.heterogeneity.productivity
+        a = collect(Float64, w.grid); z = collect(Float64, p.grid); Π = Matrix{Float64}(p.transition)
+        # only "ValueFunction" (KrusellSmith.jl:43-83) has a native kernel family so far
+        nameof(model.value_fn) == :ValueFunction || error("no native kernel family for $(model.value_fn)")
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve a z Π begin
+            m = HankModelC(w.n, p.n, model.compspec.T, 0, pointer(a), pointer(z), pointer(Π),
+                           model.params.β, model.params.γ, model.params.borrow_cons)
+            rc = ccall((:hank_create, LIBHANK), Cint, (Ref{HankModelC}, Ref{Ptr{Cvoid}}), m, ref)
+        end
+        _check(ref[], rc)
+        ctx = HankCtx(ref[], model.compspec.T - 1, w.n * p.n, w.n, p.n)
+        finalizer(c -> ccall((:hank_destroy, LIBHANK), Cint, (Ptr{Cvoid},), c.ptr), ctx)
+        ctx
+    end
+end
+
+# rows of xVals the KS value function reads (KrusellSmith.jl:53-54): r_t, w_t
+function _household_inputs(xVec_endog, model)
+    @unpack T, n_endog = model.compspec
+    xMat = reshape(xVec_endog, n_endog, T - 1)
+    ek = vars_of_type(model, :endogenous)
+    rows = [findfirst(==(k), ek) for k in (:r, :w)]
+    return xMat[rows, :]                                      # 2 x (T-1), eltype of x
+end
+
+# What BackwardIteration returns: the reference's NamedTuple-of-Vector{Matrix} surface (seqs.KD[t]),
+# copied from HBM on demand, plus what the fused sweep already knows (so ForwardIteration is free).
+struct DevicePolicySeqs{TF}
+    ctx::HankCtx; het_keys::Tuple; N::Int
+    xhh::Matrix{Float64}; dxhh::Union{Nothing,Array{Float64,3}}; value::Matrix{Float64}
+    D0::Vector{Float64}; agg::Vector{Float64}; dagg::Union{Nothing,Matrix{Float64}}
+end
+
+function _run_block(ctx::HankCtx, value, D0, xhh, dxhh)
+    _check(ctx.ptr, ccall((:hank_set_boundary, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, value, D0))
+    agg = Vector{Float64}(undef, ctx.P)
+    _check(ctx.ptr, ccall((:hank_primal, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, xhh, agg))
+    dagg = nothing
+    if dxhh !== nothing
+        N = size(dxhh, 3)
+        dagg = Matrix{Float64}(undef, ctx.P, N)
+        _check(ctx.ptr, ccall((:hank_jvp, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}), ctx.ptr, dxhh, N, dagg))
+    end
+    return agg, dagg
+end
+
+# same positional signature as BackwardIteration.jl:46-49; `ss_initial` (optional) lets the fused sweep
+# use the right D_0 straight away so that the following ForwardIteration costs nothing.
+function BackwardIteration(xVec_endog, exog_paths::NamedTuple, model::SequenceModel, ss_end; ss_initial = nothing)
+    ctx = hank_context(model)
+    TF = eltype(xVec_endog)
+    xd = _household_inputs(xVec_endog, model)
+    xhh = Matrix{Float64}(value.(xd))
+    N = TF <: Dual ? length(partials(first(xVec_endog))) : 0
+    dxhh = N > 0 ? Float64[partials(xd[k, t])[n] for k in 1:2, t in 1:ctx.P, n in 1:N] : nothing   # (n_hh, P, N)
+    D0 = ss_initial === nothing ? fill(1.0 / ctx.G, ctx.G) : Vector{Float64}(ss_initial.D)
+    val = Matrix{Float64}(ss_end.value)
+    agg, dagg = _run_block(ctx, val, D0, xhh, dxhh)
+    return DevicePolicySeqs{TF}(ctx, vars_of_type(model, :heterogeneous), N, xhh, dxhh, val, D0, agg, dagg)
+end
+
+# seqs.KD -> Vector of T-1 (Dual) matrices, as in the reference (BackwardIteration.jl:110-115)
+function Base.getproperty(s::DevicePolicySeqs{TF}, k::Symbol) where {TF}
+    k in fieldnames(DevicePolicySeqs) && return getfield(s, k)
+    ctx = getfield(s, :ctx); N = getfield(s, :N)
+    pol = Array{Float64}(undef, ctx.n_a, ctx.n_e, ctx.P)
+    _check(ctx.ptr, ccall((:hank_get_policy_seq, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.ptr, pol))
+    N == 0 && return [pol[:, :, t] for t in 1:ctx.P]
+    dpol = Array{Float64}(undef, ctx.n_a, ctx.n_e, ctx.P, N)
+    _check(ctx.ptr, ccall((:hank_get_dpolicy_seq, LIBHANK), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ctx.ptr, N, dpol))
+    return [[TF(pol[a, e, t], ntuple(n -> dpol[a, e, t, n], N)...) for a in 1:ctx.n_a, e in 1:ctx.n_e] for t in 1:ctx.P]
+end
+
+# same signature as ForwardIteration.jl:253-255 for sequences that came from BackwardIteration above
+function ForwardIteration(seqs::DevicePolicySeqs{TF}, model::SequenceModel, ss_initial) where {TF}
+    D0 = Vector{Float64}(ss_initial.D)
+    agg, dagg = seqs.agg, seqs.dagg
+    if D0 != seqs.D0      # the backward call did not know ss_initial: redo the fused sweep with the right D_0
+        agg, dagg = _run_block(seqs.ctx, seqs.value, D0, seqs.xhh, seqs.dxhh)
+    end
+    out = seqs.N == 0 ? agg : [TF(agg[t], ntuple(n -> dagg[t, n], seqs.N)...) for t in 1:length(agg)]
+    return NamedTuple{seqs.het_keys}(ntuple(_ -> out, length(seqs.het_keys)))
+end
