@@ -43,6 +43,12 @@ struct hank_ctx {
     int nbp = 0;  // row blocks of the primal kernels
     bool boundary_set = false, primal_done = false;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // the primal forward sweep runs on a side stream, concurrently with the tangent backward sweep (both only
+    // need the primal backward record); ev_side marks its completion, side_pending = the main stream has not
+    // been made to wait for it yet
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_side = nullptr;
+    bool side_pending = false;
     hipGraphExec_t g_pback = nullptr, g_pfwd = nullptr;
     hipEvent_t ev[8] = {};
     bool ev_valid[4] = {false, false, false, false};
@@ -50,6 +56,13 @@ struct hank_ctx {
     TanWork tw;
     char errmsg[512] = {0};
 };
+
+static int fail(hank_ctx *ctx, int code, const char *fmt, ...);
+static hipError_t join_side(hank_ctx *ctx) {
+    if (!ctx->side_pending) return hipSuccess;
+    ctx->side_pending = false;
+    return hipStreamWaitEvent(ctx->stream, ctx->ev_side, 0);
+}
 
 static int fail(hank_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
@@ -183,6 +196,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
 
 static int fetch_device_error(hank_ctx *ctx) {
     int e[4] = {0, 0, 0, 0};
+    HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
     if (e[0] == 0) return HANK_OK;
@@ -239,6 +253,9 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     if ((size_t)c.n_a * sizeof(int) > 150 * 1024) return fail(ctx, HANK_ERR_BAD_ARG, "n_a=%d too large for the LDS-staged lottery", c.n_a);
     HIPC(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
+    HIPC(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPC(ctx, hipEventCreate(&ctx->ev_side));
     for (int k = 0; k < 8; k++) HIPC(ctx, hipEventCreate(&ctx->ev[k]));
     HIPC(ctx, dmalloc(&ctx->d_a, c.n_a));
     HIPC(ctx, dmalloc(&ctx->d_z, c.n_e));
@@ -272,8 +289,12 @@ int hank_create(const hank_model *m, hank_ctx **out) {
 
 int hank_destroy(hank_ctx *ctx) {
     if (!ctx) return HANK_OK;
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     free_tanwork(ctx->tw);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->g_pback) (void)hipGraphExecDestroy(ctx->g_pback);
     if (ctx->g_pfwd) (void)hipGraphExecDestroy(ctx->g_pfwd);
     Record &R = ctx->R;
@@ -296,6 +317,7 @@ int hank_set_stream(hank_ctx *ctx, void *hip_stream) {
 
 int hank_sync(hank_ctx *ctx) {
     if (!ctx) return HANK_ERR_BAD_ARG;
+    HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return HANK_OK;
 }
@@ -303,6 +325,7 @@ int hank_sync(hank_ctx *ctx) {
 int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *ss_init_D) {
     if (!ctx || !ss_end_value || !ss_init_D) return fail(ctx, HANK_ERR_BAD_ARG, "null boundary pointer");
     const size_t G = ctx->c.G;
+    HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(ctx->d_ss_value, ss_end_value, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
     HIPC(ctx, hipMemcpyAsync(ctx->d_ss_D, ss_init_D, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
@@ -313,12 +336,22 @@ int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *s
     return HANK_OK;
 }
 
-static int run_primal(hank_ctx *ctx) {
+static int run_primal(hank_ctx *ctx, double *d_agg_out) {
+    HIPC(ctx, join_side(ctx));     // a previous forward sweep still reads the record this one overwrites
     HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     HIPC(ctx, hipGraphLaunch(ctx->g_pback, ctx->stream));
     HIPC(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    HIPC(ctx, hipGraphLaunch(ctx->g_pfwd, ctx->stream));
-    HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    // fork: the distribution sweep goes to the side stream; the main stream is free for the tangent
+    // backward sweep and joins (join_side) before anything that needs D_t or the aggregates
+    HIPC(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPC(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    HIPC(ctx, hipEventRecord(ctx->ev[6], ctx->side_stream));
+    HIPC(ctx, hipGraphLaunch(ctx->g_pfwd, ctx->side_stream));
+    HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->side_stream));
+    if (d_agg_out)
+        HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * ctx->c.P, hipMemcpyDeviceToDevice, ctx->side_stream));
+    HIPC(ctx, hipEventRecord(ctx->ev_side, ctx->side_stream));
+    ctx->side_pending = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = true;
     ctx->primal_done = true;
     ctx->tw.valid = false;
@@ -330,10 +363,7 @@ int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
     const size_t P = ctx->c.P;
     HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * 2 * P, hipMemcpyDeviceToDevice, ctx->stream));
-    int rc = run_primal(ctx);
-    if (rc) return rc;
-    if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
-    return HANK_OK;
+    return run_primal(ctx, d_agg_out);
 }
 
 int hank_check(hank_ctx *ctx) {
@@ -348,7 +378,7 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
     for (size_t t = 0; t < P; t++)
         if (!(1.0 + xhh[2 * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
     HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * 2 * P, hipMemcpyHostToDevice, ctx->stream));
-    int rc = run_primal(ctx);
+    int rc = run_primal(ctx, nullptr);
     if (rc) return rc;
     rc = fetch_device_error(ctx);
     if (rc) return rc;
@@ -365,6 +395,8 @@ static int run_jvp(hank_ctx *ctx) {
     HIPC(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIPC(ctx, hipGraphLaunch(w.g_back, ctx->stream));
     HIPC(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    HIPC(ctx, join_side(ctx));      // the tangent forward sweep needs D_t
+    HIPC(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     HIPC(ctx, hipGraphLaunch(w.g_fwd, ctx->stream));
     HIPC(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->ev_valid[2] = ctx->ev_valid[3] = true;
@@ -402,13 +434,14 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
 
 int hank_last_timings(hank_ctx *ctx, double out_ms[4], int32_t launches[4]) {
     if (!ctx || !out_ms) return HANK_ERR_BAD_ARG;
+    HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    const int a[4] = {0, 1, 3, 4};
+    const int a[4] = {0, 6, 3, 7}, b[4] = {1, 2, 4, 5};
     for (int k = 0; k < 4; k++) {
         out_ms[k] = -1.0;
         if (ctx->ev_valid[k]) {
             float ms = 0.f;
-            HIPC(ctx, hipEventElapsedTime(&ms, ctx->ev[a[k]], ctx->ev[a[k] + 1]));
+            HIPC(ctx, hipEventElapsedTime(&ms, ctx->ev[a[k]], ctx->ev[b[k]]));
             out_ms[k] = ms;
         }
         if (launches) launches[k] = ctx->launches[k];
@@ -419,6 +452,7 @@ int hank_last_timings(hank_ctx *ctx, double out_ms[4], int32_t launches[4]) {
 int hank_get_policy_seq(hank_ctx *ctx, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "no primal sweep has been run");
+    HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(out, ctx->R.pol, sizeof(double) * (size_t)ctx->c.P * ctx->c.G, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return HANK_OK;
@@ -427,6 +461,7 @@ int hank_get_policy_seq(hank_ctx *ctx, double *out) {
 int hank_get_dist_seq(hank_ctx *ctx, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "no primal sweep has been run");
+    HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(out, ctx->R.Dseq + ctx->c.G, sizeof(double) * (size_t)ctx->c.P * ctx->c.G, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return HANK_OK;
