@@ -73,6 +73,39 @@ def cpu_baseline(m, ss, x, Z, budget_s=12.0):
                       f"{m.heterogeneity['productivity'].n} grid, T={m.compspec.T}) in {el:.1f} s on 1 core"}
 
 
+def extra_measurements(hb, d_x, P, N, dev):
+    """second half of the BASELINE metric ("wall-clock to converged path, Krusell-Smith T=300") on
+    configs[1] (500x4), and the JVP rate of a wider tangent batch on the headline grid."""
+    import torch
+    from examples.solve_transition import solve
+    extra = {"converged_path": []}
+    for shock in (0.01, 0.8):          # mild shock, and RunMain.jl's Z_t = 1 + 0.8^t
+        try:
+            res, _ = solve(500, 4, 300, shock)
+        except Exception as e:          # noqa: BLE001 - report, do not kill the bench line
+            res = {"grid": "500x4", "T": 300, "shock": shock, "error": str(e)[:200]}
+        extra["converged_path"].append(res)
+    # wider batch on the same context (same primal): N = 256 tangents in one hank_jvp
+    Nw = 256
+    d_dx = torch.randn(2 * P * Nw, dtype=torch.float64, device=dev)
+    d_out = torch.empty(P * Nw, dtype=torch.float64, device=dev)
+    hb.jvp_dev(d_dx.data_ptr(), Nw, d_out.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        hb.primal_dev(d_x.data_ptr(), 0)
+        hb.jvp_dev(d_dx.data_ptr(), Nw, d_out.data_ptr())
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    tm = hb.last_timings()
+    G8 = hb.G * 8
+    extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el,
+                           "k_tan_back_GBs": G8 * Nw / (1e-3 * tm["tangent_backward"]["ms"] / tm["tangent_backward"]["launches"]) / 1e9,
+                           "k_tan_fwd_GBs": G8 * Nw / (1e-3 * tm["tangent_forward"]["ms"] / tm["tangent_forward"]["launches"]) / 1e9}
+    return extra
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +239,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(m, ss, x, Z)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if not args.no_extra and world == 1:
+            out["extra"] = extra_measurements(hb, d_x, P, N, dev)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -1,0 +1,56 @@
+#!/usr/bin/env python
+"""The RunMain.jl sequence (RunMain.jl:35-55, as intended — SURVEY.md §3.1) on the MI355X build:
+
+    YAML -> model -> steady state (host) -> J̅ (batched unit-tangent JVPs on the GPU)
+         -> NewtonRaphsonHANK (Boehl y-iteration; one hank_jvp per inner iteration) -> converged path
+
+    python examples/solve_transition.py [--n-a 500 --n-e 4 --T 300 --shock 0.01]
+
+`--shock 0.8` is RunMain's own Z_t = 1 + 0.8^t (an 80 % TFP jump; may not converge with the
+reference's fixed damping α = 0.5 — SURVEY.md App. B item 5)."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False):
+    import hank_amd as h
+    from conftest import ks_setup
+    t0 = time.perf_counter()
+    m, ss, _ = ks_setup(n_a, n_e, T)
+    t_ss = time.perf_counter() - t0
+    P = T - 1
+    Z = 1.0 + shock * 0.8 ** np.arange(1, P + 1)                       # RunMain.jl:22-23
+    x0 = np.tile(np.array([ss.vars[k] for k in ("Y", "KS", "r", "w")]), P)   # SteadyState.jl:277-278
+    t0 = time.perf_counter()
+    J = h.getSteadyStateJacobian(ss, m)
+    t_jac = time.perf_counter() - t0
+    h.y_Iteration.total_jvps = 0
+    t0 = time.perf_counter()
+    x = h.NewtonRaphsonHANK(x0, J, {"Z": Z}, m, ss, ss, ε=eps, verbose=verbose)
+    t_newton = time.perf_counter() - t0
+    lin = h.LinearizedFunction(x, {"Z": Z}, m, ss, ss)
+    return {"grid": f"{n_a}x{n_e}", "T": T, "shock": f"Z_t = 1 + {shock}*0.8^t", "steady_state_s": round(t_ss, 3),
+            "ss_jacobian_s": round(t_jac, 3), "newton_s": round(t_newton, 3),
+            "newton_iterations": h.NewtonRaphsonHANK.iterations, "jvps": h.y_Iteration.total_jvps, "residual_norm": float(np.linalg.norm(lin.Fx)),
+            "wall_to_converged_path_s": round(t_jac + t_newton, 3)}, x
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-a", type=int, default=500)
+    ap.add_argument("--n-e", type=int, default=4)
+    ap.add_argument("--T", type=int, default=300)
+    ap.add_argument("--shock", type=float, default=0.01)
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    out, x = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose)
+    print(json.dumps(out))

@@ -60,14 +60,36 @@ class LinearizedFunction:
 
 def _gmres(J, b, x0):
     """IterativeSolvers.gmres!(x, A, b) defaults: restart = min(20, n), reltol = sqrt(eps),
-    warm start from x (NewtonRaphson.jl:97-98)."""
+    warm start from x (NewtonRaphson.jl:97-98). `maxiter` there counts Krylov steps, scipy's counts
+    restart cycles."""
     n = len(b)
-    x, _ = spla.gmres(J, b, x0=x0, rtol=np.sqrt(np.finfo(float).eps), atol=0.0, restart=min(20, n), maxiter=n)
+    restart = min(20, n)
+    x, _ = spla.gmres(J, b, x0=x0, rtol=np.sqrt(np.finfo(float).eps), atol=0.0, restart=restart,
+                      maxiter=max(1, n // restart))
     return x
 
 
+_LU_CACHE = {}
+
+
+def _lu_solver(J):
+    """J̅ obtained from batched JVPs is a dense n x n matrix (n ≈ 1.2k): one LU factorisation, reused
+    by every inner and outer iteration, replaces the two GMRES solves per inner iteration — same
+    J̅⁻¹·b up to rounding, milliseconds instead of seconds on the host."""
+    key = id(J)
+    if key not in _LU_CACHE:
+        import scipy.linalg as sla
+        _LU_CACHE.clear()
+        A = J.toarray() if hasattr(J, "toarray") else np.asarray(J)
+        _LU_CACHE[key] = sla.lu_factor(A)
+    lu = _LU_CACHE[key]
+    import scipy.linalg as sla
+    return lambda b: sla.lu_solve(lu, b)
+
+
 def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, precond=None,
-                α: float = 1.0, γ: float = 1.5, ε: float = 1e-9, verbose: bool = False, max_inner: int = 10_000):
+                α: float = 1.0, γ: float = 1.5, ε: float = 1e-9, verbose: bool = False, max_inner: int = 10_000,
+                linear_solver: str = "lu"):
     """inner fixed-point iteration for the search direction (NewtonRaphson.jl:65-114):
     y ← y + α·J̅⁻¹(F(x) − J(x)·y), α = 0.5 hard-coded as in the reference (:102)."""
     lin = LinearizedFunction(x, exog_paths, mod, ss_initial, ss_ending)
@@ -76,10 +98,15 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
     y_old, M, R = np.ones(n), np.ones(n), np.ones(n)
     Fx = lin.Fx
     i = 1
+    solve = _lu_solver(J̅) if linear_solver == "lu" else None
     while ε < np.linalg.norm(y - y_old) and i < max_inner:
         Λxy = lin.jvp(y)
-        R = _gmres(J̅, Fx - Λxy, R)
-        M = _gmres(J̅, Λxy, M)
+        if solve is not None:
+            R = solve(Fx - Λxy)
+            M = solve(Λxy) if verbose else M       # only feeds the printed Rayleigh quotient (:101, :108-110)
+        else:
+            R = _gmres(J̅, Fx - Λxy, R)
+            M = _gmres(J̅, Λxy, M)
         ray = float(y @ M) / float(y @ y)
         α = 0.5
         y_old = y
@@ -88,17 +115,18 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
         if verbose and i % 10 == 0:
             print(f"y_Iteration {i}: α={α}  ‖y−y_old‖={np.linalg.norm(y - y_old)}  ray={ray}")
     y_Iteration.last_jvp_count = i - 1
+    y_Iteration.total_jvps = getattr(y_Iteration, "total_jvps", 0) + i - 1
     return y
 
 
 def NewtonRaphsonHANK(x_0, J̅, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, ε: float = 1e-9,
-                      verbose: bool = False):
+                      verbose: bool = False, linear_solver: str = "lu"):
     """outer Newton loop (NewtonRaphson.jl:27-46): x ← x − y until ‖y‖ ≤ ε or 100 iterations."""
     x = np.asarray(x_0, dtype=np.float64)
     y = x.copy()
     i = 1
     while ε < np.linalg.norm(y) and i < 100:
-        y = y_Iteration(J̅, x, y, exog_paths, mod, ss_initial, ss_ending, verbose=verbose)
+        y = y_Iteration(J̅, x, y, exog_paths, mod, ss_initial, ss_ending, verbose=verbose, linear_solver=linear_solver)
         x = x - y
         i += 1
         if verbose:
