@@ -15,6 +15,11 @@
 
 using namespace hank;
 
+// wealth-row groups per wave: the backward kernel's gathers are independent, so 4 groups per wave
+// keep 4x the bytes in flight and the grid fits one residency round (k_tan_back 12.5 -> 10.8 us at N=32);
+// the forward kernel's segment loops are serial per row and prefer more, shorter waves.
+constexpr int TAN_RG = 4, TAN_RGF = 1;
+
 struct TanWork {
     int N = 0;
     TanGeom g{};
@@ -157,7 +162,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
         HIPC(ctx, dmalloc(&w.dD[k], GV * N));
     }
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)(w.nbx + KV) * N));
+    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)((w.nbx + TAN_RGF - 1) / TAN_RGF + KV) * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
 
@@ -168,11 +173,11 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     // backward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    hipLaunchKernelGGL(k_tan_back, dim3(w.nbx, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, (int)P - 1, 1,
+    hipLaunchKernelGGL(k_tan_back<TAN_RG>, dim3((w.nbx + TAN_RG - 1) / TAN_RG, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, (int)P - 1, 1,
                        w.ds[1], w.ds[0], w.dpol);
     int cur = 0;
     for (int t = (int)P - 1; t >= 0; t--) {
-        hipLaunchKernelGGL(k_tan_back, dim3(w.nbx, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, t, 0,
+        hipLaunchKernelGGL(k_tan_back<TAN_RG>, dim3((w.nbx + TAN_RG - 1) / TAN_RG, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, t, 0,
                            w.ds[cur], w.ds[cur ^ 1], w.dpol);
         cur ^= 1;
     }
@@ -183,10 +188,10 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
     cur = 0;
     for (int t = 0; t < (int)P; t++) {
-        hipLaunchKernelGGL(k_tan_fwd, dim3(w.nbx + KV, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+        hipLaunchKernelGGL(k_tan_fwd<TAN_RGF>, dim3((w.nbx + TAN_RGF - 1) / TAN_RGF + KV, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
         cur ^= 1;
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, w.nbx + KV, N, w.dagg);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (w.nbx + TAN_RGF - 1) / TAN_RGF + KV, N, w.dagg);
     hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
     rc = end_capture(ctx, &w.g_fwd);
     ctx->launches[2] = (int)P + 2;

@@ -367,40 +367,70 @@ __global__ void k_tan_out(const double *__restrict__ dagg, int P, int N, double 
 // period t-1 (mix over e -> knot tangents ds_{t-1}). `first`: dV_{t+1} = 0 for the last period
 // (terminal value has zero partials, BackwardIteration.jl:85) => only the X half, from zeros.
 // ds ping-pongs between two [e][a][N] buffers that live in L2 / Infinity Cache.
+// RG = row groups per wave: a wave walks RG groups of RB = 64/NC rows with all their loads in
+// flight together (half the waves, twice the bytes in flight each: one residency round at N=32).
+template <int RG>
 __global__ void __launch_bounds__(1024)
 k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__restrict__ dxr,
            const double *__restrict__ dxw, TanGeom g, int t, int first, const double *__restrict__ dsIn,
            double *__restrict__ dsOut, double *__restrict__ dpol) {
-    __shared__ double dVsh[16 * 64];
+    __shared__ double dVsh[RG][16 * 64];
     __shared__ double Pish[256];
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
-    const int a = blockIdx.x * (64 >> g.lgNC) + rl, n = blockIdx.y * g.NC + nl;
-    const bool valid = (a < c.n_a) && (n < g.N);
+    const int RB = 64 >> g.lgNC;
+    const int n = blockIdx.y * g.NC + nl;
     const size_t N = g.N;
-    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
-    const size_t pt = (size_t)e * c.n_a + a;
-    double dV = 0.0;
-    if (valid && !first) {
-        const size_t off = (size_t)t * c.G + pt;
-        const int i = R.ib[off];
-        const double *col = dsIn + ((size_t)e * c.n_a) * N + n;
-        const double ds0 = col[(size_t)i * N], ds1 = col[(size_t)(i + 1) * N];
-        const double dr = dxr[(size_t)t * N + n], dw = dxw[(size_t)t * N + n];
-        const double dg = R.A[off] * ds0 + R.B[off] * ds1;
-        dpol[off * N + n] = dg;
-        dV = R.u[off] * dr + R.v[off] * ((c.a[a] * dr + c.z[e] * dw) - dg);
-    }
-    dVsh[e * 64 + lane] = dV;
-    __syncthreads();
     const int tx = first ? t : t - 1;   // period whose knots are produced
-    if (valid && tx >= 0) {
-        double dE = dVsh[lane] * Pish[e];
-        for (int e2 = 1; e2 < c.n_e; e2++) dE += dVsh[e2 * 64 + lane] * Pish[e + c.n_e * e2];
-        const size_t off1 = (size_t)tx * c.G + pt;
-        const double rho1 = 1.0 / (1.0 + xhh[2 * tx]);
-        const double dr1 = dxr[(size_t)tx * N + n], dw1 = dxw[(size_t)tx * N + n];
-        dsOut[pt * N + n] = R.kc[off1] * dE - rho1 * (c.z[e] * dw1 + R.s[off1] * dr1);
+    const int txc = tx < 0 ? 0 : tx;
+    int a[RG], bi[RG];
+    bool valid[RG];
+    double cA[RG], cB[RG], cu[RG], cv[RG], ck[RG], cs[RG], xa[RG];
+#pragma unroll
+    for (int q = 0; q < RG; q++) {
+        a[q] = (blockIdx.x * RG + q) * RB + rl;
+        valid[q] = (a[q] < c.n_a) && (n < g.N);
+        bi[q] = 0; cA[q] = cB[q] = cu[q] = cv[q] = ck[q] = cs[q] = xa[q] = 0.0;
+        if (valid[q]) {
+            const size_t pt = (size_t)e * c.n_a + a[q];
+            const size_t off = (size_t)t * c.G + pt, off1 = (size_t)txc * c.G + pt;
+            bi[q] = R.ib[off]; cA[q] = R.A[off]; cB[q] = R.B[off]; cu[q] = R.u[off]; cv[q] = R.v[off];
+            ck[q] = R.kc[off1]; cs[q] = R.s[off1]; xa[q] = c.a[a[q]];
+        }
+    }
+    const bool nok = n < g.N;
+    const double dr = nok ? dxr[(size_t)t * N + n] : 0.0, dw = nok ? dxw[(size_t)t * N + n] : 0.0;
+    const double dr1 = nok ? dxr[(size_t)txc * N + n] : 0.0, dw1 = nok ? dxw[(size_t)txc * N + n] : 0.0;
+    const double ze = c.z[e], rho1 = 1.0 / (1.0 + xhh[2 * txc]);
+    double d0[RG], d1[RG];
+#pragma unroll
+    for (int q = 0; q < RG; q++) {
+        d0[q] = d1[q] = 0.0;
+        if (valid[q] && !first) {
+            const double *col = dsIn + ((size_t)e * c.n_a) * N + n;
+            d0[q] = col[(size_t)bi[q] * N]; d1[q] = col[(size_t)(bi[q] + 1) * N];
+        }
+    }
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+#pragma unroll
+    for (int q = 0; q < RG; q++) {
+        double dV = 0.0;
+        if (valid[q] && !first) {
+            const double dg = cA[q] * d0[q] + cB[q] * d1[q];
+            dpol[((size_t)t * c.G + (size_t)e * c.n_a + a[q]) * N + n] = dg;
+            dV = cu[q] * dr + cv[q] * ((xa[q] * dr + ze * dw) - dg);
+        }
+        dVsh[q][e * 64 + lane] = dV;
+    }
+    __syncthreads();
+    if (tx < 0) return;
+#pragma unroll
+    for (int q = 0; q < RG; q++) {
+        if (valid[q]) {
+            double dE = dVsh[q][lane] * Pish[e];
+            for (int e2 = 1; e2 < c.n_e; e2++) dE += dVsh[q][e2 * 64 + lane] * Pish[e + c.n_e * e2];
+            dsOut[((size_t)e * c.n_a + a[q]) * N + n] = ck[q] * dE - rho1 * (ze * dw1 + cs[q] * dr1);
+        }
     }
 }
 
@@ -414,10 +444,11 @@ k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__r
 //     0's tangent is (real row 0) + sum_p (virtual row p). Everything downstream is linear, so the
 //     parts are never combined: a virtual row is a source with row 0's lottery (no own policy
 //     tangent), and its aggregate term uses pol[0, e].
+template <int RG>
 __global__ void __launch_bounds__(1024)
 k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin, double *__restrict__ dDout,
           const double *__restrict__ dpol, double *__restrict__ aggpart) {
-    __shared__ double sh[16 * 64];
+    __shared__ double sh[RG][16 * 64];
     __shared__ double Pish[256];
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
@@ -425,68 +456,83 @@ k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin,
     const int n = blockIdx.y * g.NC + nl;
     const size_t N = g.N;
     const int na = c.n_a, nav = c.n_a + KV;
-    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
     const size_t base = (size_t)t * c.G, cb = base + (size_t)e * na;
-    const double *Dprev = R.Dseq + base + (size_t)e * na, *Dnew = R.Dseq + base + c.G;
+    const double *Dprev = R.Dseq + base + (size_t)e * na, *Dnew = R.Dseq + base + c.G + (size_t)e * na;
     const double *dDc = dDin + ((size_t)e * nav) * N + n;
     const double *dpc = dpol + cb * N + n;
     const int *st = R.start + ((size_t)t * c.n_e + e) * (na + 1);
     const int clo = R.clo[(size_t)t * c.n_e + e];
-    const bool virt_block = (int)blockIdx.x >= g.nbx;
+    const int nbr = (g.nbx + RG - 1) / RG;            // regular blocks
+    const bool virt_block = (int)blockIdx.x >= nbr;
     const bool nok = n < g.N;
-    int r;          // row of the dD state this thread produces
-    bool valid;
-    double acc = 0.0;
+    int r[RG];
+    bool valid[RG];
+    double acc[RG], cp[RG], cD[RG], cdp[RG];
     if (!virt_block) {
-        r = blockIdx.x * RB + rl;
-        valid = (r < na) && nok;
-        if (valid) {
-            const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
-            for (int j = st0; j < st1; j++)
-                acc += R.lw[cb + j] * dDc[(size_t)j * N] + (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
-            for (int j = st1; j < st2; j++)
-                acc += (1.0 - R.lw[cb + j]) * dDc[(size_t)j * N] - (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
-            // row 0 not clamped: its virtual rows follow row 0's (interior) lottery
-            if (clo == 0 && st2 > 0 && (st0 == 0 || st1 == 0)) {
-                const double w0 = (st0 == 0 && st1 > 0) ? R.lw[cb] : 1.0 - R.lw[cb];
-                double v = 0.0;
-                for (int k = 0; k < KV; k++) v += dDc[(size_t)(na + k) * N];
-                acc += w0 * v;
+        int s0[RG], s1[RG], s2[RG];
+#pragma unroll
+        for (int q = 0; q < RG; q++) {
+            r[q] = (blockIdx.x * RG + q) * RB + rl;
+            valid[q] = (r[q] < na) && nok;
+            s0[q] = s1[q] = s2[q] = 0; cp[q] = cD[q] = cdp[q] = 0.0;
+            if (valid[q]) {
+                s1[q] = st[r[q]]; s2[q] = st[r[q] + 1]; s0[q] = r[q] > 0 ? st[r[q] - 1] : s1[q];
+                cp[q] = R.pol[cb + r[q]]; cD[q] = Dnew[r[q]]; cdp[q] = dpc[(size_t)r[q] * N];
             }
         }
+#pragma unroll
+        for (int q = 0; q < RG; q++) {
+            double s = 0.0;
+            if (valid[q]) {
+                for (int j = s0[q]; j < s1[q]; j++)
+                    s += R.lw[cb + j] * dDc[(size_t)j * N] + (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
+                for (int j = s1[q]; j < s2[q]; j++)
+                    s += (1.0 - R.lw[cb + j]) * dDc[(size_t)j * N] - (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
+                // row 0 not clamped: its virtual rows follow row 0's (interior) lottery
+                if (clo == 0 && s2[q] > 0 && (s0[q] == 0 || s1[q] == 0)) {
+                    const double w0 = (s0[q] == 0 && s1[q] > 0) ? R.lw[cb] : 1.0 - R.lw[cb];
+                    double v = 0.0;
+                    for (int k = 0; k < KV; k++) v += dDc[(size_t)(na + k) * N];
+                    s += w0 * v;
+                }
+            }
+            acc[q] = s;
+        }
     } else {
-        const int p = blockIdx.x - g.nbx;
-        r = na + p;
-        valid = nok && (rl == 0);
+        const int p = blockIdx.x - nbr;
+#pragma unroll
+        for (int q = 0; q < RG; q++) { r[q] = na + p; valid[q] = (q == 0) && nok && (rl == 0); acc[q] = 0.0; cD[q] = cdp[q] = 0.0; cp[q] = 0.0; }
+        cp[0] = R.pol[cb];       // a virtual row carries row 0's policy and no policy tangent of its own
+        double s = 0.0;
         if (nok && clo > 0) {
             const int M = clo + KV;                         // clamped sources, then the virtual rows
             const int lo = (int)(((long long)M * p) / KV), hi = (int)(((long long)M * (p + 1)) / KV);
             for (int i = lo + rl; i < hi; i += RB)
-                acc += dDc[(size_t)(i < clo ? i : na + (i - clo)) * N];
+                s += dDc[(size_t)(i < clo ? i : na + (i - clo)) * N];
         }
-        for (int off = 32; off >= g.NC; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        for (int off = 32; off >= g.NC; off >>= 1) s += __shfl_xor(s, off, 64);
+        acc[0] = s;
     }
-    sh[e * 64 + lane] = acc;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+#pragma unroll
+    for (int q = 0; q < RG; q++) sh[q][e * 64 + lane] = acc[q];
     __syncthreads();
     double part = 0.0;
-    if (valid) {
-        const int e2 = e;
-        double dDn = sh[lane] * Pish[c.n_e * e2];
-        for (int k = 1; k < c.n_e; k++) dDn += sh[k * 64 + lane] * Pish[k + c.n_e * e2];
-        dDout[((size_t)e2 * nav + r) * N + n] = dDn;
-        if (!virt_block) {
-            const size_t off = base + (size_t)e2 * na + r;
-            part = R.pol[off] * dDn + dpol[off * N + n] * Dnew[(size_t)e2 * na + r];
-        } else {
-            part = R.pol[base + (size_t)e2 * na] * dDn;
+#pragma unroll
+    for (int q = 0; q < RG; q++) {
+        if (valid[q]) {
+            double dDn = sh[q][lane] * Pish[c.n_e * e];      // dD_t[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
+            for (int k = 1; k < c.n_e; k++) dDn += sh[q][k * 64 + lane] * Pish[k + c.n_e * e];
+            dDout[((size_t)e * nav + r[q]) * N + n] = dDn;
+            part += cp[q] * dDn + cdp[q] * cD[q];
         }
     }
     __syncthreads();
-    sh[e * 64 + lane] = part;
+    sh[0][e * 64 + lane] = part;
     __syncthreads();
     if (e == 0) {   // sum over columns, then over the RB row lanes of each tangent
-        double s = sh[lane];
-        for (int k = 1; k < c.n_e; k++) s += sh[k * 64 + lane];
+        double s = sh[0][lane];
+        for (int k = 1; k < c.n_e; k++) s += sh[0][k * 64 + lane];
         for (int off = 32; off >= g.NC; off >>= 1) s += __shfl_xor(s, off, 64);
         if (rl == 0 && nok) aggpart[((size_t)t * gridDim.x + blockIdx.x) * N + n] = s;
     }
