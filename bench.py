@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--tangents", type=int, default=None, help="override the per-GPU tangent batch width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--split", action="store_true", help="hank_primal + hank_jvp as two calls instead of the dual-sweep hank_primal_jvp")
     args = ap.parse_args()
 
     import torch
@@ -160,8 +161,11 @@ def main():
     hb.set_stream(stream.cuda_stream)
 
     def step():
-        hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
-        hb.jvp_dev(d_dx.data_ptr(), N, d_dagg.data_ptr())
+        if args.split:      # two calls: primal sweep, then the batched JVP at the cached primal
+            hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
+            hb.jvp_dev(d_dx.data_ptr(), N, d_dagg.data_ptr())
+        else:               # one call, dual-sweep launches (what JVP(fullFunction, x, y) does in the reference)
+            hb.primal_jvp_dev(d_x.data_ptr(), d_dx.data_ptr(), N, d_agg.data_ptr(), d_dagg.data_ptr())
         if use_dist:
             dist.all_gather_into_tensor(d_all, d_dagg)  # the only exchange on the path
 
@@ -175,7 +179,8 @@ def main():
     hb.check()
     fence()
     t0 = time.perf_counter()
-    sweeps = {k: 0.0 for k in ("primal_backward", "primal_forward", "tangent_backward", "tangent_forward")}
+    sweeps = {k: 0.0 for k in (("primal_backward", "primal_forward", "tangent_backward", "tangent_forward") if args.split
+                               else ("dual_backward", "dual_forward"))}
     for _ in range(args.steps):
         step()
     fence()
@@ -191,8 +196,7 @@ def main():
     reps = 5
     acc = {k: 0.0 for k in sweeps}
     for _ in range(reps):
-        hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
-        hb.jvp_dev(d_dx.data_ptr(), N, d_dagg.data_ptr())
+        step()
         tmi = hb.last_timings()
         for k in acc:
             acc[k] += tmi[k]["ms"] / reps
@@ -204,9 +208,14 @@ def main():
         # dominant kernel: the per-period tangent kernels (k_tan_back / k_tan_fwd). One launch moves
         # the policy partials of ONE period for N directions: G*8*N algorithmic bytes
         # (B_alg = 2*P*G*8*(1+N) per batch = G*8 bytes per (sweep, period, direction)).
-        dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
-        kname = {"tangent_backward": "k_tan_back", "tangent_forward": "k_tan_fwd"}[dom]
-        bytes_per_launch = G * 8 * N
+        if args.split:
+            dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
+            kname = {"tangent_backward": "k_tan_back", "tangent_forward": "k_tan_fwd"}[dom]
+            bytes_per_launch = G * 8 * N
+        else:   # a dual-sweep launch advances the primal and the N tangents by one period: G*8*(1+N)
+            dom = max(("dual_backward", "dual_forward"), key=lambda k: acc[k])
+            kname = {"dual_backward": "k_fused_back", "dual_forward": "k_fused_fwd"}[dom]
+            bytes_per_launch = G * 8 * (1 + N)
         avg_launch_s = 1e-3 * acc[dom] / launches[dom]
         achieved = bytes_per_launch / avg_launch_s / 1e9
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
@@ -226,7 +235,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "grid": f"{n_a}x{n_e}", "T": T, "tangents_per_gpu": N,
-                       "step": "1 primal sweep + 1 batched JVP of N tangents" + (" + RCCL all-gather" if use_dist else ""),
+                       "step": ("1 primal sweep + 1 batched JVP of N tangents" if args.split else
+                                "1 dual-sweep pass: primal + N tangents (hank_primal_jvp)") + (" + RCCL all-gather" if use_dist else ""),
                        "parallelism": f"tangent-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": pmc,

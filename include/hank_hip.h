@@ -101,6 +101,16 @@ int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out);
 int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_out);
 int hank_check(hank_ctx *ctx); /* sync + fetch the device error word of the last primal          */
 
+/* hank_primal_jvp == JVP(fullFunction, x, y) exactly as the reference evaluates it: the Dual pass
+ * recomputes the primal (NewtonRaphson.jl:95; GeneralStructures.jl:546-547), so value and N partials
+ * travel together. One call = hank_primal + hank_jvp, but both recurrences advance in ONE chain of
+ * T launches per direction (the tangent sweep runs one period behind the primal sweep inside the same
+ * launches) instead of two. Leaves the context exactly as hank_primal followed by hank_jvp would.    */
+int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_t N, double *agg_out,
+                    double *dagg_out);
+int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh, int32_t N,
+                        double *d_agg_out, double *d_dagg_out);
+
 /* BackwardIteration's return value (BackwardIteration.jl:115): the policy sequence of the last
  * hank_primal, P matrices of n_a x n_e -> out[P*G]; and its partials for the last hank_jvp,
  * out[(G, P, N)] column-major (seqs_data[j][t] as Matrix{Dual}). */
@@ -131,9 +141,10 @@ int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dp
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * Device time, in milliseconds, of the sweeps of the most recent hank_primal[_dev]/hank_jvp[_dev],
  * from HIP events recorded on the context's stream around each sweep:
- *   out[0] primal backward, out[1] primal forward, out[2] tangent backward, out[3] tangent forward.
+ *   out[0] primal backward, out[1] primal forward, out[2] tangent backward, out[3] tangent forward,
+ *   out[4] dual-sweep backward, out[5] dual-sweep forward (hank_primal_jvp); -1 where not applicable.
  * launches[k] = kernel launches inside sweep k. Valid after hank_sync. */
-int hank_last_timings(hank_ctx *ctx, double out_ms[4], int32_t launches[4]);
+int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,7 @@ struct TanWork {
     double *dagg_cm = nullptr;  // (P,N) column-major
     int nbx = 0;
     hipGraphExec_t g_back = nullptr, g_fwd = nullptr;
+    hipGraphExec_t g_fback = nullptr, g_ffwd = nullptr;   // dual-sweep graphs (primal + tangents in one chain)
     bool valid = false;  // dpol holds the partials of the current primal
 };
 
@@ -55,9 +56,9 @@ struct hank_ctx {
     hipEvent_t ev_fork = nullptr, ev_side = nullptr;
     bool side_pending = false;
     hipGraphExec_t g_pback = nullptr, g_pfwd = nullptr;
-    hipEvent_t ev[8] = {};
-    bool ev_valid[4] = {false, false, false, false};
-    int launches[4] = {0, 0, 0, 0};
+    hipEvent_t ev[12] = {};
+    bool ev_valid[6] = {false, false, false, false, false, false};
+    int launches[6] = {0, 0, 0, 0, 0, 0};
     TanWork tw;
     char errmsg[512] = {0};
 };
@@ -98,6 +99,8 @@ static size_t primal_lds(const Consts &c) { return sizeof(double) * ((size_t)c.n
 static void free_tanwork(TanWork &w) {
     if (w.g_back) (void)hipGraphExecDestroy(w.g_back);
     if (w.g_fwd) (void)hipGraphExecDestroy(w.g_fwd);
+    if (w.g_fback) (void)hipGraphExecDestroy(w.g_fback);
+    if (w.g_ffwd) (void)hipGraphExecDestroy(w.g_ffwd);
     (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw);
     (void)hipFree(w.ds[0]); (void)hipFree(w.ds[1]); (void)hipFree(w.dD[0]); (void)hipFree(w.dD[1]);
     (void)hipFree(w.dpol); (void)hipFree(w.aggpart); (void)hipFree(w.dagg); (void)hipFree(w.dagg_cm);
@@ -194,8 +197,53 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (w.nbx + TAN_RGF - 1) / TAN_RGF + KV, N, w.dagg);
     hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
     rc = end_capture(ctx, &w.g_fwd);
+    if (rc) return rc;
     ctx->launches[2] = (int)P + 2;
     ctx->launches[3] = (int)P + 3;
+
+    // ---- dual-sweep graphs: the primal recurrence and the tangent recurrence advance in the SAME
+    // chain of launches, the tangent one period behind (it reads the record the previous launch wrote):
+    // T launches per direction instead of 2(T-1).
+    {
+        const dim3 pblk(RBP * c.n_e), pgrd(ctx->nbp);
+        const size_t lds = primal_lds(c);
+        const unsigned nbt = (w.nbx + TAN_RG - 1) / TAN_RG, nbf = (w.nbx + TAN_RGF - 1) / TAN_RGF + KV;
+        HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
+        hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
+        hipLaunchKernelGGL(k_egm_X, pgrd, pblk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
+                           ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, (int)P - 1);
+        int cur = 0;
+        for (int k = 0; k <= (int)P; k++) {
+            const int tp = k < (int)P ? (int)P - 1 - k : -1;
+            if (k == 0) {
+                hipLaunchKernelGGL(k_fused_back<TAN_RG>, dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
+                                   w.dxr, w.dxw, w.g, (int)P - 1, 1, w.ds[1], w.ds[0], w.dpol);
+            } else {
+                hipLaunchKernelGGL(k_fused_back<TAN_RG>, dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
+                                   w.dxr, w.dxw, w.g, (int)P - k, 0, w.ds[cur], w.ds[cur ^ 1], w.dpol);
+                cur ^= 1;
+            }
+        }
+        hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (size_t)c.n_a, s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
+        rc = end_capture(ctx, &w.g_fback);
+        if (rc) return rc;
+        HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);
+        cur = 0;
+        for (int k = 0; k <= (int)P; k++) {
+            const int tp = k < (int)P ? k : -1, tt = k - 1;
+            hipLaunchKernelGGL(k_fused_fwd<TAN_RGF>, dim3(ctx->nbp + nbf, ny), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.g, tt,
+                               w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+            if (tt >= 0) cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
+        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
+        hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
+        rc = end_capture(ctx, &w.g_ffwd);
+        ctx->launches[4] = (int)P + 5;
+        ctx->launches[5] = (int)P + 5;
+    }
     return rc;
 }
 
@@ -261,7 +309,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPC(ctx, hipEventCreate(&ctx->ev_side));
-    for (int k = 0; k < 8; k++) HIPC(ctx, hipEventCreate(&ctx->ev[k]));
+    for (int k = 0; k < 12; k++) HIPC(ctx, hipEventCreate(&ctx->ev[k]));
     HIPC(ctx, dmalloc(&ctx->d_a, c.n_a));
     HIPC(ctx, dmalloc(&ctx->d_z, c.n_e));
     HIPC(ctx, dmalloc(&ctx->d_Pi, (size_t)c.n_e * c.n_e));
@@ -307,7 +355,7 @@ int hank_destroy(hank_ctx *ctx) {
     (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
     (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < 12; k++)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -358,6 +406,7 @@ static int run_primal(hank_ctx *ctx, double *d_agg_out) {
     HIPC(ctx, hipEventRecord(ctx->ev_side, ctx->side_stream));
     ctx->side_pending = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = true;
+    ctx->ev_valid[4] = ctx->ev_valid[5] = false;
     ctx->primal_done = true;
     ctx->tw.valid = false;
     return HANK_OK;
@@ -437,12 +486,66 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
     return HANK_OK;
 }
 
-int hank_last_timings(hank_ctx *ctx, double out_ms[4], int32_t launches[4]) {
+static int run_fused(hank_ctx *ctx) {
+    TanWork &w = ctx->tw;
+    HIPC(ctx, join_side(ctx));
+    HIPC(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
+    HIPC(ctx, hipGraphLaunch(w.g_fback, ctx->stream));
+    HIPC(ctx, hipEventRecord(ctx->ev[9], ctx->stream));
+    HIPC(ctx, hipGraphLaunch(w.g_ffwd, ctx->stream));
+    HIPC(ctx, hipEventRecord(ctx->ev[10], ctx->stream));
+    ctx->ev_valid[4] = ctx->ev_valid[5] = true;
+    ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
+    ctx->primal_done = true;
+    w.valid = true;
+    return HANK_OK;
+}
+
+int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh, int32_t N, double *d_agg_out,
+                        double *d_dagg_out) {
+    if (!ctx || !d_xhh || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
+    if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    int rc = ensure_tanwork(ctx, N);
+    if (rc) return rc;
+    const size_t P = ctx->c.P;
+    HIPC(ctx, join_side(ctx));
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * 2 * P, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, d_dxhh, sizeof(double) * 2 * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = run_fused(ctx);
+    if (rc) return rc;
+    if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    return HANK_OK;
+}
+
+int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_t N, double *agg_out, double *dagg_out) {
+    if (!ctx || !xhh || !dxhh || !dagg_out || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
+    if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    const size_t P = ctx->c.P;
+    for (size_t t = 0; t < P; t++)
+        if (!(1.0 + xhh[2 * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
+    int rc = ensure_tanwork(ctx, N);
+    if (rc) return rc;
+    HIPC(ctx, join_side(ctx));
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * 2 * P, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * 2 * P * N, hipMemcpyHostToDevice, ctx->stream));
+    rc = run_fused(ctx);
+    if (rc) return rc;
+    rc = fetch_device_error(ctx);
+    if (rc) { ctx->tw.valid = false; return rc; }
+    if (agg_out) HIPC(ctx, hipMemcpyAsync(agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]) {
     if (!ctx || !out_ms) return HANK_ERR_BAD_ARG;
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    const int a[4] = {0, 6, 3, 7}, b[4] = {1, 2, 4, 5};
-    for (int k = 0; k < 4; k++) {
+    const int a[6] = {0, 6, 3, 7, 8, 9}, b[6] = {1, 2, 4, 5, 9, 10};
+    for (int k = 0; k < 6; k++) {
         out_ms[k] = -1.0;
         if (ctx->ev_valid[k]) {
             float ms = 0.f;

@@ -50,10 +50,11 @@ __device__ inline double wave_sum(double x) {
     for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
     return x;
 }
-// sum over the whole block; result valid in thread 0; red must hold >= 16 doubles
-__device__ inline double block_sum(double x, double *red) {
+// sum over the first `nthreads` threads of the block (the others must have left the kernel);
+// result valid in thread 0; red must hold >= 16 doubles
+__device__ inline double block_sum(double x, double *red, int nthreads) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nw = (blockDim.x + 63) >> 6;
+    const int nw = (nthreads + 63) >> 6;
     x = wave_sum(x);
     __syncthreads();
     if (lane == 0) red[wv] = x;
@@ -192,13 +193,15 @@ __global__ void k_egm_Y(Consts c, const double *s, double r, double w, double *p
     Vout[off] = o.V;
 }
 
-// fused sweep step: Y of period t, then X of period t-1 (value never leaves the CU)
-__global__ void k_egm_step(Consts c, Record R, const double *xhh, int t, int *err) {
-    extern __shared__ double sh[];
+// fused sweep step: Y of period t, then X of period t-1 (value never leaves the CU).
+// Body shared by k_egm_step and the dual-sweep kernel k_fused_back; runs on the first RBP*n_e
+// threads of block `bid`; sh = Vsh[n_e*RBP] + Pish[n_e*n_e].
+__device__ inline void egm_step_body(const Consts &c, const Record &R, const double *xhh, int t, int *err, int bid, double *sh) {
     double *Vsh = sh, *Pish = sh + c.n_e * RBP;
+    const int nthr = RBP * c.n_e;
     const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
-    const int a = blockIdx.x * RBP + row;
-    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    const int a = bid * RBP + row;
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
     const size_t base = (size_t)t * c.G;
     if (a < c.n_a) {
         const double r = xhh[2 * t], w = xhh[2 * t + 1];
@@ -214,6 +217,10 @@ __global__ void k_egm_step(Consts c, Record R, const double *xhh, int t, int *er
         const size_t off1 = base - c.G + (size_t)e * c.n_a + a;
         egm_X(c, Vsh, Pish, row, a, e, r1, w1, &R.s[off1], &R.kc[off1], err, t - 1);
     }
+}
+__global__ void k_egm_step(Consts c, Record R, const double *xhh, int t, int *err) {
+    extern __shared__ double sh[];
+    egm_step_body(c, R, xhh, t, err, blockIdx.x, sh);
 }
 
 // ---- Young lottery for every (period, column) at once (ForwardIteration.jl:37-78) ------------
@@ -273,13 +280,14 @@ __global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
 // ---- distribution push-forward, one period (ForwardIteration.jl:95-99, :297-308) -------------
 // block = RBP rows x n_e, thread (row, e) with row fastest (a 32-lane half-wave per column);
 // dynamic LDS: Dsh[n_e*RBP] + Pish[n_e*n_e] + red[16]
-__global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
-    extern __shared__ double sh[];
+// body shared by k_dist_step and k_fused_fwd; first RBP*n_e threads of block `bid` of `nblocks`
+__device__ inline void dist_step_body(const Consts &c, const Record &R, int t, double *aggpart, int bid, int nblocks, double *sh) {
     double *Dsh = sh, *Pish = sh + c.n_e * RBP, *red = Pish + c.n_e * c.n_e;
+    const int nthr = RBP * c.n_e;
     const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
-    const int r = blockIdx.x * RBP + row;
+    const int r = bid * RBP + row;
     const int n = c.n_a;
-    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
     const double *Dprev = R.Dseq + (size_t)t * c.G;
     const size_t base = (size_t)t * c.G;
     const double *lw = R.lw + base + (size_t)e * n, *Dp = Dprev + (size_t)e * n;
@@ -290,7 +298,7 @@ __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
         for (int j = st0; j < st1; j++) acc += lw[j] * Dp[j];
         for (int j = st1; j < st2; j++) acc += (1.0 - lw[j]) * Dp[j];
     }
-    if (blockIdx.x == 0) {  // the mass point: sum_{j < clo} D_prev[j] -> row 0, by the column's 32 lanes
+    if (bid == 0) {  // the mass point: sum_{j < clo} D_prev[j] -> row 0, by the column's 32 lanes
         const int clo = R.clo[(size_t)t * c.n_e + e];
         double part = 0.0;
         for (int j = row; j < clo; j += RBP) part += Dp[j];
@@ -308,8 +316,12 @@ __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
         R.Dseq[(size_t)(t + 1) * c.G + (size_t)e2 * n + r] = Dn;
         part = R.pol[base + (size_t)e2 * n + r] * Dn;
     }
-    const double tot = block_sum(part, red);
-    if (threadIdx.x == 0) aggpart[(size_t)t * gridDim.x + blockIdx.x] = tot;
+    const double tot = block_sum(part, red, nthr);
+    if (threadIdx.x == 0) aggpart[(size_t)t * nblocks + bid] = tot;
+}
+__global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
+    extern __shared__ double sh[];
+    dist_step_body(c, R, t, aggpart, blockIdx.x, gridDim.x, sh);
 }
 
 // zero fills as kernels (no memset nodes inside the captured graphs)
@@ -370,16 +382,14 @@ __global__ void k_tan_out(const double *__restrict__ dagg, int P, int N, double 
 // RG = row groups per wave: a wave walks RG groups of RB = 64/NC rows with all their loads in
 // flight together (half the waves, twice the bytes in flight each: one residency round at N=32).
 template <int RG>
-__global__ void __launch_bounds__(1024)
-k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__restrict__ dxr,
-           const double *__restrict__ dxw, TanGeom g, int t, int first, const double *__restrict__ dsIn,
-           double *__restrict__ dsOut, double *__restrict__ dpol) {
-    __shared__ double dVsh[RG][16 * 64];
-    __shared__ double Pish[256];
+__device__ inline void tan_back_body(const Consts &c, const Record &R, const double *__restrict__ xhh, const double *__restrict__ dxr,
+           const double *__restrict__ dxw, const TanGeom &g, int t, int first, const double *__restrict__ dsIn,
+           double *__restrict__ dsOut, double *__restrict__ dpol, int bidx, int bidy, double (*dVsh)[16 * 64], double *Pish) {
+    const int nthr = 64 * c.n_e;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
     const int RB = 64 >> g.lgNC;
-    const int n = blockIdx.y * g.NC + nl;
+    const int n = bidy * g.NC + nl;
     const size_t N = g.N;
     const int tx = first ? t : t - 1;   // period whose knots are produced
     const int txc = tx < 0 ? 0 : tx;
@@ -388,7 +398,7 @@ k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__r
     double cA[RG], cB[RG], cu[RG], cv[RG], ck[RG], cs[RG], xa[RG];
 #pragma unroll
     for (int q = 0; q < RG; q++) {
-        a[q] = (blockIdx.x * RG + q) * RB + rl;
+        a[q] = (bidx * RG + q) * RB + rl;
         valid[q] = (a[q] < c.n_a) && (n < g.N);
         bi[q] = 0; cA[q] = cB[q] = cu[q] = cv[q] = ck[q] = cs[q] = xa[q] = 0.0;
         if (valid[q]) {
@@ -411,7 +421,7 @@ k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__r
             d0[q] = col[(size_t)bi[q] * N]; d1[q] = col[(size_t)(bi[q] + 1) * N];
         }
     }
-    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
 #pragma unroll
     for (int q = 0; q < RG; q++) {
         double dV = 0.0;
@@ -434,6 +444,35 @@ k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__r
     }
 }
 
+template <int RG>
+__global__ void __launch_bounds__(1024)
+k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__restrict__ dxr,
+           const double *__restrict__ dxw, TanGeom g, int t, int first, const double *__restrict__ dsIn,
+           double *__restrict__ dsOut, double *__restrict__ dpol) {
+    __shared__ double dVsh[RG][16 * 64];
+    __shared__ double Pish[256];
+    tan_back_body<RG>(c, R, xhh, dxr, dxw, g, t, first, dsIn, dsOut, dpol, blockIdx.x, blockIdx.y, dVsh, Pish);
+}
+
+// the dual-sweep backward launch: blocks [0, nbp) of grid row 0 run the PRIMAL EGM step of period tp,
+// the others the tangent step of period tt = tp + 1 (whose record the previous launch wrote) — both
+// recurrences advance in one chain of T launches instead of two.
+template <int RG>
+__global__ void __launch_bounds__(1024)
+k_fused_back(Consts c, Record R, const double *__restrict__ xhh, int *err, int tp, int nbp,
+             const double *__restrict__ dxr, const double *__restrict__ dxw, TanGeom g, int tt, int first,
+             const double *__restrict__ dsIn, double *__restrict__ dsOut, double *__restrict__ dpol) {
+    __shared__ double dVsh[RG][16 * 64];
+    __shared__ double Pish[256];
+    if ((int)blockIdx.x < nbp) {
+        if (blockIdx.y != 0 || tp < 0 || (int)threadIdx.x >= RBP * c.n_e) return;
+        egm_step_body(c, R, xhh, tp, err, blockIdx.x, &dVsh[0][0]);   // needs n_e*RBP + n_e^2 <= 768 doubles
+        return;
+    }
+    if (tt < 0) return;
+    tan_back_body<RG>(c, R, xhh, dxr, dxw, g, tt, first, dsIn, dsOut, dpol, blockIdx.x - nbp, blockIdx.y, dVsh, Pish);
+}
+
 // one forward period: segment gather of the lottery tangent (ForwardIteration.jl:37-99 under
 // Dual), mix over e, aggregate dagg_t = sum(dpol_t * D_t + pol_t * dD_t) with the POST-transition
 // D_t (:301-307). dD state: [e][n_a + KV][N].
@@ -445,15 +484,13 @@ k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__r
 //     parts are never combined: a virtual row is a source with row 0's lottery (no own policy
 //     tangent), and its aggregate term uses pol[0, e].
 template <int RG>
-__global__ void __launch_bounds__(1024)
-k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin, double *__restrict__ dDout,
-          const double *__restrict__ dpol, double *__restrict__ aggpart) {
-    __shared__ double sh[RG][16 * 64];
-    __shared__ double Pish[256];
+__device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanGeom &g, int t, const double *__restrict__ dDin, double *__restrict__ dDout,
+          const double *__restrict__ dpol, double *__restrict__ aggpart, int bidx, int bidy, int nbx_total, double (*sh)[16 * 64], double *Pish) {
+    const int nthr = 64 * c.n_e;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
     const int RB = 64 >> g.lgNC;
-    const int n = blockIdx.y * g.NC + nl;
+    const int n = bidy * g.NC + nl;
     const size_t N = g.N;
     const int na = c.n_a, nav = c.n_a + KV;
     const size_t base = (size_t)t * c.G, cb = base + (size_t)e * na;
@@ -463,7 +500,7 @@ k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin,
     const int *st = R.start + ((size_t)t * c.n_e + e) * (na + 1);
     const int clo = R.clo[(size_t)t * c.n_e + e];
     const int nbr = (g.nbx + RG - 1) / RG;            // regular blocks
-    const bool virt_block = (int)blockIdx.x >= nbr;
+    const bool virt_block = bidx >= nbr;
     const bool nok = n < g.N;
     int r[RG];
     bool valid[RG];
@@ -472,7 +509,7 @@ k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin,
         int s0[RG], s1[RG], s2[RG];
 #pragma unroll
         for (int q = 0; q < RG; q++) {
-            r[q] = (blockIdx.x * RG + q) * RB + rl;
+            r[q] = (bidx * RG + q) * RB + rl;
             valid[q] = (r[q] < na) && nok;
             s0[q] = s1[q] = s2[q] = 0; cp[q] = cD[q] = cdp[q] = 0.0;
             if (valid[q]) {
@@ -499,7 +536,7 @@ k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin,
             acc[q] = s;
         }
     } else {
-        const int p = blockIdx.x - nbr;
+        const int p = bidx - nbr;
 #pragma unroll
         for (int q = 0; q < RG; q++) { r[q] = na + p; valid[q] = (q == 0) && nok && (rl == 0); acc[q] = 0.0; cD[q] = cdp[q] = 0.0; cp[q] = 0.0; }
         cp[0] = R.pol[cb];       // a virtual row carries row 0's policy and no policy tangent of its own
@@ -513,7 +550,7 @@ k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin,
         for (int off = 32; off >= g.NC; off >>= 1) s += __shfl_xor(s, off, 64);
         acc[0] = s;
     }
-    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
+    for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
 #pragma unroll
     for (int q = 0; q < RG; q++) sh[q][e * 64 + lane] = acc[q];
     __syncthreads();
@@ -534,8 +571,35 @@ k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin,
         double s = sh[0][lane];
         for (int k = 1; k < c.n_e; k++) s += sh[0][k * 64 + lane];
         for (int off = 32; off >= g.NC; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (rl == 0 && nok) aggpart[((size_t)t * gridDim.x + blockIdx.x) * N + n] = s;
+        if (rl == 0 && nok) aggpart[((size_t)t * nbx_total + bidx) * N + n] = s;
     }
+}
+
+template <int RG>
+__global__ void __launch_bounds__(1024)
+k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin, double *__restrict__ dDout,
+          const double *__restrict__ dpol, double *__restrict__ aggpart) {
+    __shared__ double sh[RG][16 * 64];
+    __shared__ double Pish[256];
+    tan_fwd_body<RG>(c, R, g, t, dDin, dDout, dpol, aggpart, blockIdx.x, blockIdx.y, gridDim.x, sh, Pish);
+}
+
+// the dual-sweep forward launch: blocks [0, nbp) of grid row 0 run the PRIMAL distribution step of
+// period tp, the others the tangent step of period tt = tp - 1 (D_{tt+1} was written by the previous launch).
+template <int RG>
+__global__ void __launch_bounds__(1024)
+k_fused_fwd(Consts c, Record R, int tp, int nbp, double *__restrict__ paggpart, TanGeom g, int tt,
+            const double *__restrict__ dDin, double *__restrict__ dDout, const double *__restrict__ dpol,
+            double *__restrict__ aggpart) {
+    __shared__ double sh[RG][16 * 64];
+    __shared__ double Pish[256];
+    if ((int)blockIdx.x < nbp) {
+        if (blockIdx.y != 0 || tp < 0 || (int)threadIdx.x >= RBP * c.n_e) return;
+        dist_step_body(c, R, tp, paggpart, blockIdx.x, nbp, &sh[0][0]);
+        return;
+    }
+    if (tt < 0) return;
+    tan_fwd_body<RG>(c, R, g, tt, dDin, dDout, dpol, aggpart, blockIdx.x - nbp, blockIdx.y, gridDim.x - nbp, sh, Pish);
 }
 
 // ---- granular tangent halves (hank_backward_step_dual) ---------------------------------------
@@ -626,7 +690,7 @@ __global__ void k_colsum(const double *aggterm, int G, int W, double *out) {
     const int k = blockIdx.x;
     double s = 0.0;
     for (int pt = threadIdx.x; pt < G; pt += blockDim.x) s += aggterm[(size_t)pt * W + k];
-    const double tot = block_sum(s, red);
+    const double tot = block_sum(s, red, blockDim.x);
     if (threadIdx.x == 0) out[k] = tot;
 }
 

@@ -22,6 +22,7 @@ HANK_VF_KRUSELL_SMITH = 0
 ABI_SYMBOLS = (
     "hank_create", "hank_destroy", "hank_last_error", "hank_n_hh", "hank_set_stream", "hank_sync",
     "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
+    "hank_primal_jvp", "hank_primal_jvp_dev",
     "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
     "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings",
 )
@@ -86,6 +87,8 @@ def load_library() -> C.CDLL:
     lib.hank_primal_dev.argtypes = [vp, vp, vp]
     lib.hank_jvp_dev.argtypes = [vp, vp, i32, vp]
     lib.hank_check.argtypes = [vp]
+    lib.hank_primal_jvp.argtypes = [vp, dp, dp, i32, dp, dp]
+    lib.hank_primal_jvp_dev.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.hank_get_policy_seq.argtypes = [vp, dp]
     lib.hank_get_dpolicy_seq.argtypes = [vp, i32, dp]
     lib.hank_get_dist_seq.argtypes = [vp, dp]
@@ -189,6 +192,23 @@ class HouseholdBlock:
         self._chk(self._lib.hank_jvp(self._ctx, _p(dx), N, _p(out)))
         return out
 
+    def primal_jvp(self, xhh, dxhh):
+        """value and N partials in one dual-sweep pass (what JVP(fullFunction, x, y) does in the reference)."""
+        x = _f(xhh, (self.n_hh, self.P))
+        dx = np.asarray(dxhh, dtype=np.float64)
+        if dx.ndim == 2:
+            dx = dx[:, :, None]
+        N = dx.shape[2]
+        dx = _f(dx, (self.n_hh, self.P, N))
+        agg = np.empty(self.P)
+        dagg = np.empty((self.P, N), order="F")
+        self._chk(self._lib.hank_primal_jvp(self._ctx, _p(x), _p(dx), N, _p(agg), _p(dagg)))
+        return agg, dagg
+
+    def primal_jvp_dev(self, d_xhh_ptr: int, d_dxhh_ptr: int, N: int, d_agg_ptr: int = 0, d_dagg_ptr: int = 0):
+        self._chk(self._lib.hank_primal_jvp_dev(self._ctx, C.c_void_p(d_xhh_ptr), C.c_void_p(d_dxhh_ptr), int(N),
+                                                C.c_void_p(d_agg_ptr), C.c_void_p(d_dagg_ptr)))
+
     def primal_dev(self, d_xhh_ptr: int, d_agg_ptr: int = 0):
         self._chk(self._lib.hank_primal_dev(self._ctx, C.c_void_p(d_xhh_ptr), C.c_void_p(d_agg_ptr)))
 
@@ -196,10 +216,10 @@ class HouseholdBlock:
         self._chk(self._lib.hank_jvp_dev(self._ctx, C.c_void_p(d_dxhh_ptr), int(N), C.c_void_p(d_dagg_ptr)))
 
     def last_timings(self):
-        ms = (C.c_double * 4)()
-        ln = (C.c_int32 * 4)()
+        ms = (C.c_double * 6)()
+        ln = (C.c_int32 * 6)()
         self._chk(self._lib.hank_last_timings(self._ctx, ms, ln))
-        names = ("primal_backward", "primal_forward", "tangent_backward", "tangent_forward")
+        names = ("primal_backward", "primal_forward", "tangent_backward", "tangent_forward", "dual_backward", "dual_forward")
         return {k: {"ms": ms[i], "launches": ln[i]} for i, k in enumerate(names)}
 
     def policy_seq(self) -> np.ndarray:

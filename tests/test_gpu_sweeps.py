@@ -114,3 +114,21 @@ def test_knots_error_from_the_sweep(hank):
         hb.jvp(np.zeros((2, 99, 1)))          # no valid primal -> refused
     hb.set_boundary(ss.value, ss.D)
     hb.primal(x[2:4])                          # context recovers
+
+
+def test_dual_sweep_equals_primal_then_jvp(hank):
+    """hank_primal_jvp (primal and tangents advancing in the same chain of launches) gives bit for bit
+    what hank_primal followed by hank_jvp gives, and leaves the same record behind."""
+    for (na, ne, T, N) in [(50, 2, 100, 3), (37, 3, 9, 5), (500, 4, 300, 1)]:
+        m, ss, orc = ks_setup(na, ne, T)
+        P = T - 1
+        x, Z = ks_paths(m, ss, "x1", 0.05)
+        y = np.random.default_rng(5).standard_normal((2, P, N))
+        hb = hank.household_block(m)
+        hb.set_boundary(ss.value, ss.D)
+        agg0 = hb.primal(x[2:4]); dagg0 = hb.jvp(y); pol0 = hb.policy_seq(); dpol0 = hb.dpolicy_seq(N)
+        hb.primal(x[2:4] * 1.01)                       # scramble the record
+        agg1, dagg1 = hb.primal_jvp(x[2:4], y)
+        assert np.array_equal(agg0, agg1) and np.array_equal(dagg0, dagg1)
+        assert np.array_equal(pol0, hb.policy_seq()) and np.array_equal(dpol0, hb.dpolicy_seq(N))
+        assert np.array_equal(hb.jvp(y), dagg0)        # the record it leaves serves later JVPs
