@@ -115,8 +115,10 @@ def BackwardIteration(xVec_endog, exog_paths, model: SequenceModel, ss_end, ss_i
     xhh, dxhh = household_inputs(xVec_endog, exog_paths, model)
     D0 = np.asarray(ss_initial.D, dtype=np.float64) if ss_initial is not None else np.full(hb.G, 1.0 / hb.G)
     hb.set_boundary(ss_end.value, D0)
-    agg = hb.primal(xhh)
-    dagg = hb.jvp(dxhh) if dxhh is not None else None
+    if dxhh is not None:      # a Dual pass carries value and partials together, like the reference's JVP
+        agg, dagg = hb.primal_jvp(xhh, dxhh)
+    else:
+        agg, dagg = hb.primal(xhh), None
     hb._generation = getattr(hb, "_generation", 0) + 1
     hb._last = {"agg": agg, "dagg": dagg, "D0": D0, "xhh": xhh, "dxhh": dxhh,
                 "value": np.array(ss_end.value, dtype=np.float64, copy=True)}

@@ -335,14 +335,20 @@ __global__ void k_zero_f64(double *p, size_t n) {
 
 // out[t*N + n] = sum_b parts[(t*nb + b)*N + n]; one block per (t, 64-wide tangent chunk), four
 // groups of 64 lanes stride over the row blocks, fixed combination order: bitwise reproducible
-__global__ void k_reduce_parts(const double *parts, int nb, int N, double *out) {
+__global__ void k_reduce_parts(const double *__restrict__ parts, int nb, int N, double *__restrict__ out) {
     __shared__ double red[256];
     const int t = blockIdx.x, nl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n = blockIdx.y * 64 + nl;
     double s = 0.0;
     if (n < N) {
         const double *p = parts + (size_t)t * nb * N + n;
-        for (int b = g; b < nb; b += 4) s += p[(size_t)b * N];
+        int b = g;
+        for (; b + 28 < nb; b += 32) {      // 8 independent loads in flight per lane
+            const double v0 = p[(size_t)b * N], v1 = p[(size_t)(b + 4) * N], v2 = p[(size_t)(b + 8) * N], v3 = p[(size_t)(b + 12) * N];
+            const double v4 = p[(size_t)(b + 16) * N], v5 = p[(size_t)(b + 20) * N], v6 = p[(size_t)(b + 24) * N], v7 = p[(size_t)(b + 28) * N];
+            s += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+        }
+        for (; b < nb; b += 4) s += p[(size_t)b * N];
     }
     red[threadIdx.x] = s;
     __syncthreads();
