@@ -111,11 +111,13 @@ __device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, do
         i = n - 2;
     } else {
         int lo = -1, hi = n;  // sc[lo] <= x < sc[hi]
+        bool have = false;    // vlo/vhi hold sc[lo], sc[hi] (bracket found by the first probe)
+        double vlo = 0.0, vhi = 0.0;
         if (guess >= 0) {
             const int p = guess < n - 1 ? guess : n - 2;
             const double sp = sc[p], sp1 = sc[p + 1];
             if (sp <= x && x < sp1) {
-                lo = p; hi = p + 1;
+                lo = p; hi = p + 1; have = true; vlo = sp; vhi = sp1;   // the usual case: one round trip
             } else if (sp1 <= x) {          // gallop up
                 lo = p + 1;
                 for (int step = 1;; step <<= 1) {
@@ -137,7 +139,7 @@ __device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, do
             if (sc[mid] <= x) lo = mid; else hi = mid;
         }
         i = lo < 0 ? 0 : (lo > n - 2 ? n - 2 : lo);
-        const double si = sc[i], sj = sc[i + 1];
+        const double si = have ? vlo : sc[i], sj = have ? vhi : sc[i + 1];
         const double h = sj - si;
         const double f = (x - si) / h;
         const double ai = c.a[i], aj = c.a[i + 1];
@@ -510,25 +512,31 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
     const bool nok = n < g.N;
     int r[RG];
     bool valid[RG];
-    double acc[RG], cp[RG], cD[RG], cdp[RG];
+    double acc[RG], cp[RG];
+    double pagg = 0.0;    // sum of dpol_j * D_t[j] over the sources this thread owns
     if (!virt_block) {
         int s0[RG], s1[RG], s2[RG];
 #pragma unroll
         for (int q = 0; q < RG; q++) {
             r[q] = (bidx * RG + q) * RB + rl;
             valid[q] = (r[q] < na) && nok;
-            s0[q] = s1[q] = s2[q] = 0; cp[q] = cD[q] = cdp[q] = 0.0;
+            s0[q] = s1[q] = s2[q] = 0; cp[q] = 0.0;
             if (valid[q]) {
                 s1[q] = st[r[q]]; s2[q] = st[r[q] + 1]; s0[q] = r[q] > 0 ? st[r[q] - 1] : s1[q];
-                cp[q] = R.pol[cb + r[q]]; cD[q] = Dnew[r[q]]; cdp[q] = dpc[(size_t)r[q] * N];
+                cp[q] = R.pol[cb + r[q]];
             }
         }
 #pragma unroll
         for (int q = 0; q < RG; q++) {
             double s = 0.0;
             if (valid[q]) {
-                for (int j = s0[q]; j < s1[q]; j++)
-                    s += R.lw[cb + j] * dDc[(size_t)j * N] + (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
+                for (int j = s0[q]; j < s1[q]; j++) {
+                    // every unclamped source sits in exactly one FIRST segment: its aggregate term
+                    // dpol_j * D_t[j] is taken here, so dpol is not read a third time by its own row
+                    const double dpj = dpc[(size_t)j * N];
+                    s += R.lw[cb + j] * dDc[(size_t)j * N] + (dpj * R.ig[cb + j]) * Dprev[j];
+                    pagg += dpj * Dnew[j];
+                }
                 for (int j = s1[q]; j < s2[q]; j++)
                     s += (1.0 - R.lw[cb + j]) * dDc[(size_t)j * N] - (dpc[(size_t)j * N] * R.ig[cb + j]) * Dprev[j];
                 // row 0 not clamped: its virtual rows follow row 0's (interior) lottery
@@ -544,16 +552,19 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
     } else {
         const int p = bidx - nbr;
 #pragma unroll
-        for (int q = 0; q < RG; q++) { r[q] = na + p; valid[q] = (q == 0) && nok && (rl == 0); acc[q] = 0.0; cD[q] = cdp[q] = 0.0; cp[q] = 0.0; }
+        for (int q = 0; q < RG; q++) { r[q] = na + p; valid[q] = (q == 0) && nok && (rl == 0); acc[q] = 0.0; cp[q] = 0.0; }
         cp[0] = R.pol[cb];       // a virtual row carries row 0's policy and no policy tangent of its own
         double s = 0.0;
         if (nok && clo > 0) {
             const int M = clo + KV;                         // clamped sources, then the virtual rows
             const int lo = (int)(((long long)M * p) / KV), hi = (int)(((long long)M * (p + 1)) / KV);
-            for (int i = lo + rl; i < hi; i += RB)
+            for (int i = lo + rl; i < hi; i += RB) {
                 s += dDc[(size_t)(i < clo ? i : na + (i - clo)) * N];
+                if (i < clo) pagg += dpc[(size_t)i * N] * Dnew[i];   // clamped sources: policy partial is 0 except on a knot tie
+            }
         }
-        for (int off = 32; off >= g.NC; off >>= 1) s += __shfl_xor(s, off, 64);
+        for (int off = 32; off >= g.NC; off >>= 1) { s += __shfl_xor(s, off, 64); pagg += __shfl_xor(pagg, off, 64); }
+        if (rl != 0) pagg = 0.0;
         acc[0] = s;
     }
     for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
@@ -567,9 +578,10 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
             double dDn = sh[q][lane] * Pish[c.n_e * e];      // dD_t[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
             for (int k = 1; k < c.n_e; k++) dDn += sh[q][k * 64 + lane] * Pish[k + c.n_e * e];
             dDout[((size_t)e * nav + r[q]) * N + n] = dDn;
-            part += cp[q] * dDn + cdp[q] * cD[q];
+            part += cp[q] * dDn;
         }
     }
+    part += pagg;
     __syncthreads();
     sh[0][e * 64 + lane] = part;
     __syncthreads();
