@@ -408,12 +408,39 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
     for (int q = 0; q < RG; q++) {
         a[q] = (bidx * RG + q) * RB + rl;
         valid[q] = (a[q] < c.n_a) && (n < g.N);
-        bi[q] = 0; cA[q] = cB[q] = cu[q] = cv[q] = ck[q] = cs[q] = xa[q] = 0.0;
-        if (valid[q]) {
-            const size_t pt = (size_t)e * c.n_a + a[q];
+    }
+    if (RG * RB <= 64) {
+        // The record coefficients depend on the wealth row only: a wave touches RG*RB <= 64 distinct rows,
+        // so ONE lane-sparse load per array (lane L fetches row L) plus cross-lane broadcasts replaces RG
+        // full-width loads per array — the vector memory path is the scarce unit here (a full 64-lane
+        // 8-byte load occupies it for >= 8 clocks however few distinct addresses it has).
+        const int qa = lane / RB, ra = lane - qa * RB;
+        const int al = (bidx * RG + qa) * RB + ra;
+        int l_i = 0;
+        double l_A = 0, l_B = 0, l_u = 0, l_v = 0, l_k = 0, l_s = 0, l_x = 0;
+        if (lane < RG * RB && al < c.n_a) {
+            const size_t pt = (size_t)e * c.n_a + al;
             const size_t off = (size_t)t * c.G + pt, off1 = (size_t)txc * c.G + pt;
-            bi[q] = R.ib[off]; cA[q] = R.A[off]; cB[q] = R.B[off]; cu[q] = R.u[off]; cv[q] = R.v[off];
-            ck[q] = R.kc[off1]; cs[q] = R.s[off1]; xa[q] = c.a[a[q]];
+            l_i = R.ib[off]; l_A = R.A[off]; l_B = R.B[off]; l_u = R.u[off]; l_v = R.v[off];
+            l_k = R.kc[off1]; l_s = R.s[off1]; l_x = c.a[al];
+        }
+#pragma unroll
+        for (int q = 0; q < RG; q++) {
+            const int src = q * RB + rl;
+            bi[q] = __shfl(l_i, src, 64); cA[q] = __shfl(l_A, src, 64); cB[q] = __shfl(l_B, src, 64);
+            cu[q] = __shfl(l_u, src, 64); cv[q] = __shfl(l_v, src, 64); ck[q] = __shfl(l_k, src, 64);
+            cs[q] = __shfl(l_s, src, 64); xa[q] = __shfl(l_x, src, 64);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < RG; q++) {
+            bi[q] = 0; cA[q] = cB[q] = cu[q] = cv[q] = ck[q] = cs[q] = xa[q] = 0.0;
+            if (valid[q]) {
+                const size_t pt = (size_t)e * c.n_a + a[q];
+                const size_t off = (size_t)t * c.G + pt, off1 = (size_t)txc * c.G + pt;
+                bi[q] = R.ib[off]; cA[q] = R.A[off]; cB[q] = R.B[off]; cu[q] = R.u[off]; cv[q] = R.v[off];
+                ck[q] = R.kc[off1]; cs[q] = R.s[off1]; xa[q] = c.a[a[q]];
+            }
         }
     }
     const bool nok = n < g.N;
