@@ -44,6 +44,16 @@ __device__ inline void set_err(int *err, int code, int t, int e, int j) {
 
 __device__ inline bool pow_domain_error(double v, double y) { return (v < 0.0) && (y != floor(y)); }
 
+// x^y with the exponents CRRA utility produces most often taken through correctly rounded
+// division / square root (γ = 2: y = -1/2 and y = -2; γ = 1: y = -1) — a generic fp64 pow is a few
+// hundred VALU instructions on the primal sweep's critical path. Same value as pow() to an ulp.
+__device__ inline double pow_crra(double x, double y) {
+    if (y == -0.5) return 1.0 / sqrt(x);
+    if (y == -2.0) return 1.0 / (x * x);
+    if (y == -1.0) return 1.0 / x;
+    return pow(x, y);
+}
+
 // ---- block reductions (64-wide wavefronts) ------------------------------------------------
 __device__ inline double wave_sum(double x) {
 #pragma unroll
@@ -76,7 +86,7 @@ __device__ inline void egm_X(const Consts &c, const double *Vsh, const double *P
     const double bE = E * c.beta;
     const double ex = -1.0 / c.gamma;
     if (pow_domain_error(bE, ex)) set_err(err, ERR_DOMAIN, t, e, a);
-    const double cm = pow(bE, ex);
+    const double cm = pow_crra(bE, ex);
     const double rho = 1.0 / (1.0 + r);
     *s_out = rho * ((cm - w * c.z[e]) + c.a[a]);
     // d cmat/dE = beta*ex*(bE)^(ex-1)  (Dual^Real, ForwardDiff dual.jl:563-572)
@@ -158,7 +168,7 @@ __device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, do
     const double opr = 1.0 + r;
     const double cg = (opr * x + w * c.z[e]) - g;
     if (pow_domain_error(cg, -c.gamma)) set_err(err, ERR_DOMAIN, t, e, a);
-    const double u = pow(cg, -c.gamma);
+    const double u = pow_crra(cg, -c.gamma);
     o.g = g;
     o.A = A;
     o.B = B;
