@@ -326,6 +326,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, dmalloc(&R.ib, P * G)); HIPC(ctx, dmalloc(&R.lo, P * G));
     HIPC(ctx, dmalloc(&R.start, P * (size_t)c.n_e * (c.n_a + 1)));
     HIPC(ctx, dmalloc(&R.clo, P * (size_t)c.n_e));
+    HIPC(ctx, dmalloc(&R.lwg, P * G));
     HIPC(ctx, dmalloc(&ctx->d_ss_value, G));
     ctx->d_ss_D = R.Dseq;
     ctx->nbp = (c.n_a + RBP - 1) / RBP;
@@ -352,7 +353,7 @@ int hank_destroy(hank_ctx *ctx) {
     if (ctx->g_pfwd) (void)hipGraphExecDestroy(ctx->g_pfwd);
     Record &R = ctx->R;
     (void)hipFree(R.s); (void)hipFree(R.kc); (void)hipFree(R.A); (void)hipFree(R.B); (void)hipFree(R.u); (void)hipFree(R.v);
-    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo);
+    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo); (void)hipFree(R.lwg);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
     (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 12; k++)
