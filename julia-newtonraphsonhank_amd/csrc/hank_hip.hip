@@ -130,7 +130,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
                        ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1);
     for (int t = P - 1; t >= 0; t--)
         hipLaunchKernelGGL(k_egm_step, grd, blk, lds, s, c, ctx->R, ctx->d_xhh, t, ctx->d_err);
-    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (size_t)c.n_a, s, c, ctx->R, P * c.n_e, ctx->d_err);
+    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, P * c.n_e, ctx->d_err);
     int rc = end_capture(ctx, &ctx->g_pback);
     if (rc) return rc;
     // forward
@@ -225,7 +225,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
                 cur ^= 1;
             }
         }
-        hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (size_t)c.n_a, s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
+        hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
         rc = end_capture(ctx, &w.g_fback);
         if (rc) return rc;
         HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -303,7 +303,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     c.beta = m->beta; c.gamma = m->gamma; c.bc = m->borrow_cons;
     ctx->T = m->T;
     const size_t P = c.P, G = c.G;
-    if ((size_t)c.n_a * sizeof(int) > 150 * 1024) return fail(ctx, HANK_ERR_BAD_ARG, "n_a=%d too large for the LDS-staged lottery", c.n_a);
+    if ((2 * (size_t)c.n_a + 2) * sizeof(int) > 150 * 1024) return fail(ctx, HANK_ERR_BAD_ARG, "n_a=%d too large for the LDS-staged lottery", c.n_a);
     HIPC(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIPC(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
@@ -326,7 +326,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, dmalloc(&R.ib, P * G)); HIPC(ctx, dmalloc(&R.lo, P * G));
     HIPC(ctx, dmalloc(&R.start, P * (size_t)c.n_e * (c.n_a + 1)));
     HIPC(ctx, dmalloc(&R.clo, P * (size_t)c.n_e));
-    HIPC(ctx, dmalloc(&R.lwg, P * G));
+    HIPC(ctx, dmalloc(&R.lwg, P * G)); HIPC(ctx, dmalloc(&R.seg, P * G));
     HIPC(ctx, dmalloc(&ctx->d_ss_value, G));
     ctx->d_ss_D = R.Dseq;
     ctx->nbp = (c.n_a + RBP - 1) / RBP;
@@ -353,7 +353,7 @@ int hank_destroy(hank_ctx *ctx) {
     if (ctx->g_pfwd) (void)hipGraphExecDestroy(ctx->g_pfwd);
     Record &R = ctx->R;
     (void)hipFree(R.s); (void)hipFree(R.kc); (void)hipFree(R.A); (void)hipFree(R.B); (void)hipFree(R.u); (void)hipFree(R.v);
-    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo); (void)hipFree(R.lwg);
+    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo); (void)hipFree(R.lwg); (void)hipFree(R.seg);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
     (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 12; k++)

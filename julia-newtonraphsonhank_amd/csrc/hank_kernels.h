@@ -30,6 +30,7 @@ struct Consts {
 struct Record {
     double *s, *kc, *A, *B, *u, *v, *pol, *lw, *ig, *Dseq;
     int *ib, *lo, *start, *clo;
+    int4 *seg;      // per target row: {start[r-1], start[r], start[r+1], -} — ONE read instead of three
     double2 *lwg;   // per source row: {lottery weight w, weight-tangent factor ig * D_{t-1}} — ONE 16-byte read per source in the forward tangent kernel
 };
 
@@ -281,13 +282,19 @@ __global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
     const int clo = sh_clo;
     if (threadIdx.x == 0) R.clo[col] = clo;
     int *st = R.start + (size_t)col * (n + 1);
+    int *shst = shlo + n;          // segment offsets staged in LDS (second half of the dynamic LDS)
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const int prev = j ? shlo[j - 1] : -1, cur = shlo[j];
         if (cur < prev) set_err(err, ERR_NONMONO, t, e, j);
-        for (int r = (prev < 0 ? 0 : prev + 1); r <= cur; r++) st[r] = j;   // j >= clo whenever cur >= 0
+        for (int r = (prev < 0 ? 0 : prev + 1); r <= cur; r++) shst[r] = j;   // j >= clo whenever cur >= 0
         if (j == n - 1)
-            for (int r = (cur < 0 ? 0 : cur + 1); r <= n; r++) st[r] = n;
+            for (int r = (cur < 0 ? 0 : cur + 1); r <= n; r++) shst[r] = n;
     }
+    __syncthreads();
+    for (int r = threadIdx.x; r <= n; r += blockDim.x) st[r] = shst[r];
+    // per target row: its three segment bounds in one 16-byte record
+    for (int r = threadIdx.x; r < n; r += blockDim.x)
+        R.seg[base + r] = make_int4(r > 0 ? shst[r - 1] : shst[r], shst[r], shst[r + 1], 0);
 }
 
 // ---- distribution push-forward, one period (ForwardIteration.jl:95-99, :297-308) -------------
@@ -561,7 +568,8 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
             valid[q] = (r[q] < na) && nok;
             s0[q] = s1[q] = s2[q] = 0; cp[q] = 0.0;
             if (valid[q]) {
-                s1[q] = st[r[q]]; s2[q] = st[r[q] + 1]; s0[q] = r[q] > 0 ? st[r[q] - 1] : s1[q];
+                const int4 sg = R.seg[cb + r[q]];
+                s0[q] = sg.x; s1[q] = sg.y; s2[q] = sg.z;
                 cp[q] = R.pol[cb + r[q]];
             }
         }
