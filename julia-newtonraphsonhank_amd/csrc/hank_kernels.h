@@ -77,6 +77,29 @@ __device__ inline double block_sum(double x, double *red, int nthreads) {
     return r;
 }
 
+// dev knob: how the big streaming stores leave the CU (0 plain, 1 sc1 write-through, 2 nontemporal)
+#ifndef HANK_ST_DPOL
+#define HANK_ST_DPOL 1
+#endif
+#ifndef HANK_ST_STATE
+#define HANK_ST_STATE 1
+#endif
+#ifndef HANK_ST_REC
+#define HANK_ST_REC 0
+#endif
+template <int MODE>
+__device__ __forceinline__ void st_mode(double *p, double x) {
+    if (MODE == 1) __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (MODE == 2) __builtin_nontemporal_store(x, p);
+    else *p = x;
+}
+template <int MODE>
+__device__ __forceinline__ void st_mode_i(int *p, int x) {
+    if (MODE == 1) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (MODE == 2) __builtin_nontemporal_store(x, p);
+    else *p = x;
+}
+
 // ---- EGM step, split in the two halves that fuse across the period boundary ------------------
 // X half (KrusellSmith.jl:59-62): from V_{t+1} (all e2 of this row, in LDS) to the endogenous
 // knot s_t[a,e] and kc = d s / d E  (= rho * d c / d E).
@@ -90,9 +113,9 @@ __device__ inline void egm_X(const Consts &c, const double *Vsh, const double *P
     if (pow_domain_error(bE, ex)) set_err(err, ERR_DOMAIN, t, e, a);
     const double cm = pow_crra(bE, ex);
     const double rho = 1.0 / (1.0 + r);
-    *s_out = rho * ((cm - w * c.z[e]) + c.a[a]);
+    st_mode<HANK_ST_REC>(s_out, rho * ((cm - w * c.z[e]) + c.a[a]));
     // d cmat/dE = beta*ex*(bE)^(ex-1)  (Dual^Real, ForwardDiff dual.jl:563-572)
-    *kc_out = rho * (c.beta * ex * (cm / bE));
+    st_mode<HANK_ST_REC>(kc_out, rho * (c.beta * ex * (cm / bE)));
 }
 
 // Y half (KrusellSmith.jl:66-80): interpolate the policy on the exogenous grid point a from the
@@ -222,7 +245,8 @@ __device__ inline void egm_step_body(const Consts &c, const Record &R, const dou
         const int guess = (t + 1 < c.P) ? R.ib[base + c.G + (size_t)e * c.n_a + a] : -1;
         const YOut o = egm_Y(c, R.s + base + (size_t)e * c.n_a, a, e, r, w, err, t, guess);
         const size_t off = base + (size_t)e * c.n_a + a;
-        R.pol[off] = o.g; R.ib[off] = o.ib; R.A[off] = o.A; R.B[off] = o.B; R.u[off] = o.u; R.v[off] = o.v;
+        st_mode<HANK_ST_REC>(&R.pol[off], o.g); st_mode_i<HANK_ST_REC>(&R.ib[off], o.ib); st_mode<HANK_ST_REC>(&R.A[off], o.A);
+        st_mode<HANK_ST_REC>(&R.B[off], o.B); st_mode<HANK_ST_REC>(&R.u[off], o.u); st_mode<HANK_ST_REC>(&R.v[off], o.v);
         Vsh[e * RBP + row] = o.V;
     }
     __syncthreads();
@@ -334,7 +358,7 @@ __device__ inline void dist_step_body(const Consts &c, const Record &R, int t, d
         const int e2 = e;  // D_new[r,e2] = sum_e D_mid[r,e] * Pi[e,e2]
         double Dn = 0.0;
         for (int k = 0; k < c.n_e; k++) Dn += Dsh[k * RBP + row] * Pish[k + c.n_e * e2];
-        R.Dseq[(size_t)(t + 1) * c.G + (size_t)e2 * n + r] = Dn;
+        st_mode<HANK_ST_REC>(&R.Dseq[(size_t)(t + 1) * c.G + (size_t)e2 * n + r], Dn);
         part = R.pol[base + (size_t)e2 * n + r] * Dn;
     }
     const double tot = block_sum(part, red, nthr);
@@ -383,6 +407,7 @@ __global__ void k_reduce_parts(const double *__restrict__ parts, int nb, int N, 
 // is the fastest LDS index). Block = 64*n_e threads.
 // KV virtual rows per column (rows n_a .. n_a+KV-1 of the dD state) hold partial sums of the
 // mass-point row 0 — see k_tan_fwd.
+
 constexpr int KV = 16;
 struct TanGeom { int N, NC, lgNC, nbx; };   // nbx = regular row blocks = ceil(n_a / (64/NC))
 
@@ -481,7 +506,7 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
         double dV = 0.0;
         if (valid[q] && !first) {
             const double dg = cA[q] * d0[q] + cB[q] * d1[q];
-            dpol[((size_t)t * c.G + (size_t)e * c.n_a + a[q]) * N + n] = dg;
+            st_mode<HANK_ST_DPOL>(&dpol[((size_t)t * c.G + (size_t)e * c.n_a + a[q]) * N + n], dg);
             dV = cu[q] * dr + cv[q] * ((xa[q] * dr + ze * dw) - dg);
         }
         dVsh[q][e * 64 + lane] = dV;
@@ -493,7 +518,7 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
         if (valid[q]) {
             double dE = dVsh[q][lane] * Pish[e];
             for (int e2 = 1; e2 < c.n_e; e2++) dE += dVsh[q][e2 * 64 + lane] * Pish[e + c.n_e * e2];
-            dsOut[((size_t)e * c.n_a + a[q]) * N + n] = ck[q] * dE - rho1 * (ze * dw1 + cs[q] * dr1);
+            st_mode<HANK_ST_STATE>(&dsOut[((size_t)e * c.n_a + a[q]) * N + n], ck[q] * dE - rho1 * (ze * dw1 + cs[q] * dr1));
         }
     }
 }
@@ -548,10 +573,9 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
     const size_t N = g.N;
     const int na = c.n_a, nav = c.n_a + KV;
     const size_t base = (size_t)t * c.G, cb = base + (size_t)e * na;
-    const double *Dprev = R.Dseq + base + (size_t)e * na, *Dnew = R.Dseq + base + c.G + (size_t)e * na;
+    const double *Dnew = R.Dseq + base + c.G + (size_t)e * na;
     const double *dDc = dDin + ((size_t)e * nav) * N + n;
     const double *dpc = dpol + cb * N + n;
-    const int *st = R.start + ((size_t)t * c.n_e + e) * (na + 1);
     const int clo = R.clo[(size_t)t * c.n_e + e];
     const int nbr = (g.nbx + RG - 1) / RG;            // regular blocks
     const bool virt_block = bidx >= nbr;
@@ -627,7 +651,7 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
         if (valid[q]) {
             double dDn = sh[q][lane] * Pish[c.n_e * e];      // dD_t[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
             for (int k = 1; k < c.n_e; k++) dDn += sh[q][k * 64 + lane] * Pish[k + c.n_e * e];
-            dDout[((size_t)e * nav + r[q]) * N + n] = dDn;
+            st_mode<HANK_ST_STATE>(&dDout[((size_t)e * nav + r[q]) * N + n], dDn);
             part += cp[q] * dDn;
         }
     }
