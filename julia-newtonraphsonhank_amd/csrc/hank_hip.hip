@@ -17,8 +17,10 @@ using namespace hank;
 
 // wealth-row groups per wave: the backward kernel's gathers are independent, so 4 groups per wave
 // keep 4x the bytes in flight and the grid fits one residency round (k_tan_back 12.5 -> 10.8 us at N=32);
-// the forward kernel's segment loops are serial per row and prefer more, shorter waves.
-constexpr int TAN_RG = 4, TAN_RGF = 1;
+// the forward kernel's segment loops are serial per row and prefer more, shorter waves — one group
+// per wave up to N = 64, two from N = 128 on (forward sweep 20.8 -> 18.5 ms at N = 256; 3.7 -> 4.0 ms at N = 32).
+constexpr int TAN_RG = 4;
+static inline int tan_rgf(int N) { return N >= 128 ? 2 : 1; }
 
 struct TanWork {
     int N = 0;
@@ -165,7 +167,9 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
         HIPC(ctx, dmalloc(&w.dD[k], GV * N));
     }
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)((w.nbx + TAN_RGF - 1) / TAN_RGF + KV) * N));
+    const int RGF = tan_rgf(N);
+    const unsigned nbf = (w.nbx + RGF - 1) / RGF + KV;   // forward blocks: regular + mass-point
+    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
 
@@ -191,10 +195,11 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
     cur = 0;
     for (int t = 0; t < (int)P; t++) {
-        hipLaunchKernelGGL(k_tan_fwd<TAN_RGF>, dim3((w.nbx + TAN_RGF - 1) / TAN_RGF + KV, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+        if (RGF == 2) hipLaunchKernelGGL(k_tan_fwd<2>, dim3(nbf, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+        else hipLaunchKernelGGL(k_tan_fwd<1>, dim3(nbf, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
         cur ^= 1;
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (w.nbx + TAN_RGF - 1) / TAN_RGF + KV, N, w.dagg);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
     hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
     rc = end_capture(ctx, &w.g_fwd);
     if (rc) return rc;
@@ -207,7 +212,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     {
         const dim3 pblk(RBP * c.n_e), pgrd(ctx->nbp);
         const size_t lds = primal_lds(c);
-        const unsigned nbt = (w.nbx + TAN_RG - 1) / TAN_RG, nbf = (w.nbx + TAN_RGF - 1) / TAN_RGF + KV;
+        const unsigned nbt = (w.nbx + TAN_RG - 1) / TAN_RG;
         HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
         hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
@@ -233,8 +238,10 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
         cur = 0;
         for (int k = 0; k <= (int)P; k++) {
             const int tp = k < (int)P ? k : -1, tt = k - 1;
-            hipLaunchKernelGGL(k_fused_fwd<TAN_RGF>, dim3(ctx->nbp + nbf, ny), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.g, tt,
-                               w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+            if (RGF == 2) hipLaunchKernelGGL(k_fused_fwd<2>, dim3(ctx->nbp + nbf, ny), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.g, tt,
+                                             w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+            else hipLaunchKernelGGL(k_fused_fwd<1>, dim3(ctx->nbp + nbf, ny), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.g, tt,
+                                    w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
             if (tt >= 0) cur ^= 1;
         }
         hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
