@@ -15,11 +15,12 @@
 
 using namespace hank;
 
-// wealth-row groups per wave: the backward kernel's gathers are independent, so 4 groups per wave
-// keep 4x the bytes in flight and the grid fits one residency round (k_tan_back 12.5 -> 10.8 us at N=32);
+// wealth-row groups per wave: the backward kernel's gathers are independent, so 2 groups per wave keep
+// twice the bytes in flight (1 / 2 / 4 groups: dual backward sweep 3.61 / 3.12 / 3.32 ms at N=32,
+// 16.3 / 12.6 / 14.8 ms at N=256; 4 was best before the coefficient loads went lane-sparse);
 // the forward kernel's segment loops are serial per row and prefer more, shorter waves — one group
 // per wave up to N = 64, two from N = 128 on (forward sweep 20.8 -> 18.5 ms at N = 256; 3.7 -> 4.0 ms at N = 32).
-constexpr int TAN_RG = 4;
+constexpr int TAN_RG = 2;
 static inline int tan_rgf(int N) { return N >= 128 ? 2 : 1; }
 
 struct TanWork {

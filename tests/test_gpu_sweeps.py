@@ -65,9 +65,12 @@ def test_config2_500x4_T300(hank, N):
 
 
 def test_odd_sizes_and_nonpow2_batch(hank):
-    """ragged shapes: n_a not a multiple of any block size, n_e = 3, N = 5 and N = 70 (> one chunk)."""
+    """ragged shapes: n_a not a multiple of any block size, n_e = 3, N = 5, N = 70 (> one chunk) and
+    N = 130 (the wide-batch geometry of the forward kernel: two row groups per wave from N = 128 on)."""
     run_case(hank, 37, 3, 9, 5, "x1", 0.05)
     run_case(hank, 37, 3, 9, 70, "x1", 0.05, check_policies=False)
+    run_case(hank, 37, 3, 9, 130, "x1", 0.05, check_policies=False)
+    run_case(hank, 50, 2, 100, 130, "x1", 0.8, check_policies=False)
 
 
 def test_golden_full_pipeline(hank):
