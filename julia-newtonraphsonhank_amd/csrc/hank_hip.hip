@@ -21,11 +21,16 @@ using namespace hank;
 // the forward kernel's segment loops are serial per row and prefer more, shorter waves — one group
 // per wave up to N = 64, two from N = 128 on (forward sweep 20.8 -> 18.5 ms at N = 256; 3.7 -> 4.0 ms at N = 32).
 constexpr int TAN_RG = 2;
-static inline int tan_rgf(int N) { return N >= 128 ? 2 : 1; }
+static inline int tan_rgf(int NV) { return NV >= 128 ? 2 : 1; }   // NV = lanes' worth of directions
+static inline int tan_lane_width(int N, int forward) {
+    const char *e = getenv(forward ? "HANK_LANE_WIDTH_F" : "HANK_LANE_WIDTH_B");   // dev knobs
+    const int want = e ? atoi(e) : 2;
+    return (want == 2 && N % 2 == 0) ? 2 : 1;
+}
 
 struct TanWork {
     int N = 0;
-    TanGeom g{};
+    TanGeom g{}, gf{};   // lane geometry of the backward / forward tangent kernels
     double *dxhh = nullptr;   // (2,P,N) staging for the host-pointer entry
     double *dxr = nullptr, *dxw = nullptr;
     double *ds[2] = {nullptr, nullptr};
@@ -34,7 +39,7 @@ struct TanWork {
     double *aggpart = nullptr;
     double *dagg = nullptr;     // [P][N]
     double *dagg_cm = nullptr;  // (P,N) column-major
-    int nbx = 0;
+    int nbx = 0, nbxf = 0;
     hipGraphExec_t g_back = nullptr, g_fwd = nullptr;
     hipGraphExec_t g_fback = nullptr, g_ffwd = nullptr;   // dual-sweep graphs (primal + tangents in one chain)
     bool valid = false;  // dpol holds the partials of the current primal
@@ -147,46 +152,32 @@ static int build_primal_graphs(hank_ctx *ctx) {
     return rc;
 }
 
-static int ensure_tanwork(hank_ctx *ctx, int N) {
-    TanWork &w = ctx->tw;
-    if (w.N == N && w.g_back) return HANK_OK;
-    free_tanwork(w);
+// Captures the four tangent graphs for lane type VT (double: one direction per lane; double2: two).
+template <typename VT, typename VF>
+static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGF, unsigned nbf) {
     const Consts &c = ctx->c;
-    const size_t P = c.P, G = c.G;
-    w.N = N;
-    int NC = 1, lg = 0;
-    while (NC < N && NC < 64) { NC <<= 1; lg++; }
-    const int RB = 64 / NC;
-    w.nbx = (c.n_a + RB - 1) / RB;
-    w.g.N = N; w.g.NC = NC; w.g.lgNC = lg; w.g.nbx = w.nbx;
-    const size_t GV = (size_t)(c.n_a + KV) * c.n_e;   // dD state carries KV virtual rows per column
-    HIPC(ctx, dmalloc(&w.dxhh, 2 * P * N));
-    HIPC(ctx, dmalloc(&w.dxr, P * N));
-    HIPC(ctx, dmalloc(&w.dxw, P * N));
-    for (int k = 0; k < 2; k++) {
-        HIPC(ctx, dmalloc(&w.ds[k], G * N));
-        HIPC(ctx, dmalloc(&w.dD[k], GV * N));
-    }
-    HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-    const int RGF = tan_rgf(N);
-    const unsigned nbf = (w.nbx + RGF - 1) / RGF + KV;   // forward blocks: regular + mass-point
-    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
-    HIPC(ctx, dmalloc(&w.dagg, P * N));
-    HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
-
+    const size_t P = c.P;
+    const int N = w.N;
+    const size_t GV = (size_t)(c.n_a + KV) * c.n_e;
     hipStream_t s = ctx->own_stream;
     const dim3 blk(64 * c.n_e);
-    const unsigned ny = (N + NC - 1) / NC;
+    const unsigned ny = (w.g.N + w.g.NC - 1) / w.g.NC, nyf = (w.gf.N + w.gf.NC - 1) / w.gf.NC;
     const int PN = (int)(P * N);
+    const VT *dxr = reinterpret_cast<const VT *>(w.dxr), *dxw = reinterpret_cast<const VT *>(w.dxw);
+    VT *ds[2] = {reinterpret_cast<VT *>(w.ds[0]), reinterpret_cast<VT *>(w.ds[1])};
+    VF *dD[2] = {reinterpret_cast<VF *>(w.dD[0]), reinterpret_cast<VF *>(w.dD[1])};
+    VT *dpol = reinterpret_cast<VT *>(w.dpol);
+    VF *dpolf = reinterpret_cast<VF *>(w.dpol), *aggpart = reinterpret_cast<VF *>(w.aggpart);
+    const unsigned nbt = (w.nbx + TAN_RG - 1) / TAN_RG;
     // backward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    hipLaunchKernelGGL(k_tan_back<TAN_RG>, dim3((w.nbx + TAN_RG - 1) / TAN_RG, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, (int)P - 1, 1,
-                       w.ds[1], w.ds[0], w.dpol);
+    hipLaunchKernelGGL((k_tan_back<TAN_RG, VT>), dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, w.g, (int)P - 1, 1,
+                       ds[1], ds[0], dpol);
     int cur = 0;
     for (int t = (int)P - 1; t >= 0; t--) {
-        hipLaunchKernelGGL(k_tan_back<TAN_RG>, dim3((w.nbx + TAN_RG - 1) / TAN_RG, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, w.dxr, w.dxw, w.g, t, 0,
-                           w.ds[cur], w.ds[cur ^ 1], w.dpol);
+        hipLaunchKernelGGL((k_tan_back<TAN_RG, VT>), dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, w.g, t, 0,
+                           ds[cur], ds[cur ^ 1], dpol);
         cur ^= 1;
     }
     int rc = end_capture(ctx, &w.g_back);
@@ -196,8 +187,8 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
     cur = 0;
     for (int t = 0; t < (int)P; t++) {
-        if (RGF == 2) hipLaunchKernelGGL(k_tan_fwd<2>, dim3(nbf, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
-        else hipLaunchKernelGGL(k_tan_fwd<1>, dim3(nbf, ny), blk, 0, s, c, ctx->R, w.g, t, w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
+        if (RGF == 2) hipLaunchKernelGGL((k_tan_fwd<2, VF>), dim3(nbf, nyf), blk, 0, s, c, ctx->R, w.gf, t, dD[cur], dD[cur ^ 1], dpolf, aggpart);
+        else hipLaunchKernelGGL((k_tan_fwd<1, VF>), dim3(nbf, nyf), blk, 0, s, c, ctx->R, w.gf, t, dD[cur], dD[cur ^ 1], dpolf, aggpart);
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
@@ -210,49 +201,83 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     // ---- dual-sweep graphs: the primal recurrence and the tangent recurrence advance in the SAME
     // chain of launches, the tangent one period behind (it reads the record the previous launch wrote):
     // T launches per direction instead of 2(T-1).
-    {
-        const dim3 pblk(RBP * c.n_e), pgrd(ctx->nbp);
-        const size_t lds = primal_lds(c);
-        const unsigned nbt = (w.nbx + TAN_RG - 1) / TAN_RG;
-        HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
-        hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-        hipLaunchKernelGGL(k_egm_X, pgrd, pblk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
-                           ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, (int)P - 1);
-        int cur = 0;
-        for (int k = 0; k <= (int)P; k++) {
-            const int tp = k < (int)P ? (int)P - 1 - k : -1;
-            if (k == 0) {
-                hipLaunchKernelGGL(k_fused_back<TAN_RG>, dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
-                                   w.dxr, w.dxw, w.g, (int)P - 1, 1, w.ds[1], w.ds[0], w.dpol);
-            } else {
-                hipLaunchKernelGGL(k_fused_back<TAN_RG>, dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
-                                   w.dxr, w.dxw, w.g, (int)P - k, 0, w.ds[cur], w.ds[cur ^ 1], w.dpol);
-                cur ^= 1;
-            }
+    const dim3 pblk(RBP * c.n_e), pgrd(ctx->nbp);
+    const size_t lds = primal_lds(c);
+    HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
+    hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
+    hipLaunchKernelGGL(k_egm_X, pgrd, pblk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
+                       ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, (int)P - 1);
+    cur = 0;
+    for (int k = 0; k <= (int)P; k++) {
+        const int tp = k < (int)P ? (int)P - 1 - k : -1;
+        if (k == 0) {
+            hipLaunchKernelGGL((k_fused_back<TAN_RG, VT>), dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
+                               dxr, dxw, w.g, (int)P - 1, 1, ds[1], ds[0], dpol);
+        } else {
+            hipLaunchKernelGGL((k_fused_back<TAN_RG, VT>), dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
+                               dxr, dxw, w.g, (int)P - k, 0, ds[cur], ds[cur ^ 1], dpol);
+            cur ^= 1;
         }
-        hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
-        rc = end_capture(ctx, &w.g_fback);
-        if (rc) return rc;
-        HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);
-        cur = 0;
-        for (int k = 0; k <= (int)P; k++) {
-            const int tp = k < (int)P ? k : -1, tt = k - 1;
-            if (RGF == 2) hipLaunchKernelGGL(k_fused_fwd<2>, dim3(ctx->nbp + nbf, ny), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.g, tt,
-                                             w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
-            else hipLaunchKernelGGL(k_fused_fwd<1>, dim3(ctx->nbp + nbf, ny), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.g, tt,
-                                    w.dD[cur], w.dD[cur ^ 1], w.dpol, w.aggpart);
-            if (tt >= 0) cur ^= 1;
-        }
-        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
-        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
-        hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
-        rc = end_capture(ctx, &w.g_ffwd);
-        ctx->launches[4] = (int)P + 5;
-        ctx->launches[5] = (int)P + 5;
     }
+    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
+    rc = end_capture(ctx, &w.g_fback);
+    if (rc) return rc;
+    HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);
+    cur = 0;
+    for (int k = 0; k <= (int)P; k++) {
+        const int tp = k < (int)P ? k : -1, tt = k - 1;
+        if (RGF == 2) hipLaunchKernelGGL((k_fused_fwd<2, VF>), dim3(ctx->nbp + nbf, nyf), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.gf, tt,
+                                         dD[cur], dD[cur ^ 1], dpolf, aggpart);
+        else hipLaunchKernelGGL((k_fused_fwd<1, VF>), dim3(ctx->nbp + nbf, nyf), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.gf, tt,
+                                dD[cur], dD[cur ^ 1], dpolf, aggpart);
+        if (tt >= 0) cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
+    hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
+    rc = end_capture(ctx, &w.g_ffwd);
+    ctx->launches[4] = (int)P + 5;
+    ctx->launches[5] = (int)P + 5;
     return rc;
+}
+
+static int ensure_tanwork(hank_ctx *ctx, int N) {
+    TanWork &w = ctx->tw;
+    if (w.N == N && w.g_back) return HANK_OK;
+    free_tanwork(w);
+    const Consts &c = ctx->c;
+    const size_t P = c.P, G = c.G;
+    w.N = N;
+    // an even batch can run two directions per lane (16-byte accesses): the [..][N] layout is the same, so
+    // each sweep picks its own lane width
+    const int VB = tan_lane_width(N, 0), VF = tan_lane_width(N, 1);
+    auto geom = [&](int V, TanGeom &g) {
+        const int NV = N / V;
+        int NC = 1, lg = 0;
+        while (NC < NV && NC < 64) { NC <<= 1; lg++; }
+        const int RB = 64 / NC;
+        g.N = NV; g.NC = NC; g.lgNC = lg; g.nbx = (c.n_a + RB - 1) / RB;
+    };
+    geom(VB, w.g); geom(VF, w.gf);
+    w.nbx = w.g.nbx; w.nbxf = w.gf.nbx;
+    const size_t GV = (size_t)(c.n_a + KV) * c.n_e;   // dD state carries KV virtual rows per column
+    HIPC(ctx, dmalloc(&w.dxhh, 2 * P * N));
+    HIPC(ctx, dmalloc(&w.dxr, P * N));
+    HIPC(ctx, dmalloc(&w.dxw, P * N));
+    for (int k = 0; k < 2; k++) {
+        HIPC(ctx, dmalloc(&w.ds[k], G * N));
+        HIPC(ctx, dmalloc(&w.dD[k], GV * N));
+    }
+    HIPC(ctx, dmalloc(&w.dpol, P * G * N));
+    const int RGF = tan_rgf(w.gf.N);
+    const unsigned nbf = (w.nbxf + RGF - 1) / RGF + KV;   // forward blocks: regular + mass-point
+    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
+    HIPC(ctx, dmalloc(&w.dagg, P * N));
+    HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
+    if (VB == 2) return VF == 2 ? capture_tangent_graphs<double2, double2>(ctx, w, RGF, nbf) : capture_tangent_graphs<double2, double>(ctx, w, RGF, nbf);
+    return VF == 2 ? capture_tangent_graphs<double, double2>(ctx, w, RGF, nbf) : capture_tangent_graphs<double, double>(ctx, w, RGF, nbf);
 }
 
 static int fetch_device_error(hank_ctx *ctx) {

@@ -433,10 +433,38 @@ __global__ void k_tan_out(const double *__restrict__ dagg, int P, int N, double 
 // ds ping-pongs between two [e][a][N] buffers that live in L2 / Infinity Cache.
 // RG = row groups per wave: a wave walks RG groups of RB = 64/NC rows with all their loads in
 // flight together (half the waves, twice the bytes in flight each: one residency round at N=32).
-template <int RG>
-__device__ inline void tan_back_body(const Consts &c, const Record &R, const double *__restrict__ xhh, const double *__restrict__ dxr,
-           const double *__restrict__ dxw, const TanGeom &g, int t, int first, const double *__restrict__ dsIn,
-           double *__restrict__ dsOut, double *__restrict__ dpol, int bidx, int bidy, double (*dVsh)[16 * 64], double *Pish) {
+// Tangent lanes are templated on VT = double (one direction per lane) or double2 (two adjacent directions per
+// lane: every state / dpol access is a 16-byte one, half the vector-memory instructions per byte; the memory
+// layout [..][N] is the same, N even). g.N / g.NC count VT elements.
+__device__ __forceinline__ void vzero(double &v) { v = 0.0; }
+__device__ __forceinline__ void vzero(double2 &v) { v.x = 0.0; v.y = 0.0; }
+__device__ __forceinline__ double vshfl_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ double2 vshfl_xor(double2 v, int m) { return make_double2(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64)); }
+template <int MODE>
+__device__ __forceinline__ void st_mode(double2 *p, double2 v) {
+    if (MODE == 1) {
+        // one 16-byte write-through store (there is no 16-byte atomic store to spell it with); the trailing
+        // s_nop keeps the compiler's next instruction off the data registers until the store has read them
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        d2_t d = {v.x, v.y};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+    } else if (MODE == 2) {
+        __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
+    } else {
+        *p = v;
+    }
+}
+__device__ __forceinline__ double2 vmul(double a, double2 v) { return make_double2(a * v.x, a * v.y); }
+__device__ __forceinline__ double vmul(double a, double v) { return a * v; }
+__device__ __forceinline__ double2 vadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double vadd(double a, double b) { return a + b; }
+__device__ __forceinline__ double2 vsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double vsub(double a, double b) { return a - b; }
+
+template <int RG, typename VT>
+__device__ inline void tan_back_body(const Consts &c, const Record &R, const double *__restrict__ xhh, const VT *__restrict__ dxr,
+           const VT *__restrict__ dxw, const TanGeom &g, int t, int first, const VT *__restrict__ dsIn,
+           VT *__restrict__ dsOut, VT *__restrict__ dpol, int bidx, int bidy, VT (*dVsh)[16 * 64], double *Pish) {
     const int nthr = 64 * c.n_e;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
@@ -488,26 +516,31 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
         }
     }
     const bool nok = n < g.N;
-    const double dr = nok ? dxr[(size_t)t * N + n] : 0.0, dw = nok ? dxw[(size_t)t * N + n] : 0.0;
-    const double dr1 = nok ? dxr[(size_t)txc * N + n] : 0.0, dw1 = nok ? dxw[(size_t)txc * N + n] : 0.0;
+    VT dr, dw, dr1, dw1;
+    vzero(dr); vzero(dw); vzero(dr1); vzero(dw1);
+    if (nok) {
+        dr = dxr[(size_t)t * N + n]; dw = dxw[(size_t)t * N + n];
+        dr1 = dxr[(size_t)txc * N + n]; dw1 = dxw[(size_t)txc * N + n];
+    }
     const double ze = c.z[e], rho1 = 1.0 / (1.0 + xhh[2 * txc]);
-    double d0[RG], d1[RG];
+    VT d0[RG], d1[RG];
 #pragma unroll
     for (int q = 0; q < RG; q++) {
-        d0[q] = d1[q] = 0.0;
+        vzero(d0[q]); vzero(d1[q]);
         if (valid[q] && !first) {
-            const double *col = dsIn + ((size_t)e * c.n_a) * N + n;
+            const VT *col = dsIn + ((size_t)e * c.n_a) * N + n;
             d0[q] = col[(size_t)bi[q] * N]; d1[q] = col[(size_t)(bi[q] + 1) * N];
         }
     }
     for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
 #pragma unroll
     for (int q = 0; q < RG; q++) {
-        double dV = 0.0;
+        VT dV;
+        vzero(dV);
         if (valid[q] && !first) {
-            const double dg = cA[q] * d0[q] + cB[q] * d1[q];
+            const VT dg = vadd(vmul(cA[q], d0[q]), vmul(cB[q], d1[q]));
             st_mode<HANK_ST_DPOL>(&dpol[((size_t)t * c.G + (size_t)e * c.n_a + a[q]) * N + n], dg);
-            dV = cu[q] * dr + cv[q] * ((xa[q] * dr + ze * dw) - dg);
+            dV = vadd(vmul(cu[q], dr), vmul(cv[q], vsub(vadd(vmul(xa[q], dr), vmul(ze, dw)), dg)));
         }
         dVsh[q][e * 64 + lane] = dV;
     }
@@ -516,40 +549,41 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
 #pragma unroll
     for (int q = 0; q < RG; q++) {
         if (valid[q]) {
-            double dE = dVsh[q][lane] * Pish[e];
-            for (int e2 = 1; e2 < c.n_e; e2++) dE += dVsh[q][e2 * 64 + lane] * Pish[e + c.n_e * e2];
-            st_mode<HANK_ST_STATE>(&dsOut[((size_t)e * c.n_a + a[q]) * N + n], ck[q] * dE - rho1 * (ze * dw1 + cs[q] * dr1));
+            VT dE = vmul(Pish[e], dVsh[q][lane]);
+            for (int e2 = 1; e2 < c.n_e; e2++) dE = vadd(dE, vmul(Pish[e + c.n_e * e2], dVsh[q][e2 * 64 + lane]));
+            st_mode<HANK_ST_STATE>(&dsOut[((size_t)e * c.n_a + a[q]) * N + n],
+                                   vsub(vmul(ck[q], dE), vmul(rho1, vadd(vmul(ze, dw1), vmul(cs[q], dr1)))));
         }
     }
 }
 
-template <int RG>
+template <int RG, typename VT>
 __global__ void __launch_bounds__(1024)
-k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const double *__restrict__ dxr,
-           const double *__restrict__ dxw, TanGeom g, int t, int first, const double *__restrict__ dsIn,
-           double *__restrict__ dsOut, double *__restrict__ dpol) {
-    __shared__ double dVsh[RG][16 * 64];
+k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const VT *__restrict__ dxr,
+           const VT *__restrict__ dxw, TanGeom g, int t, int first, const VT *__restrict__ dsIn,
+           VT *__restrict__ dsOut, VT *__restrict__ dpol) {
+    __shared__ VT dVsh[RG][16 * 64];
     __shared__ double Pish[256];
-    tan_back_body<RG>(c, R, xhh, dxr, dxw, g, t, first, dsIn, dsOut, dpol, blockIdx.x, blockIdx.y, dVsh, Pish);
+    tan_back_body<RG, VT>(c, R, xhh, dxr, dxw, g, t, first, dsIn, dsOut, dpol, blockIdx.x, blockIdx.y, dVsh, Pish);
 }
 
 // the dual-sweep backward launch: blocks [0, nbp) of grid row 0 run the PRIMAL EGM step of period tp,
 // the others the tangent step of period tt = tp + 1 (whose record the previous launch wrote) — both
 // recurrences advance in one chain of T launches instead of two.
-template <int RG>
+template <int RG, typename VT>
 __global__ void __launch_bounds__(1024)
 k_fused_back(Consts c, Record R, const double *__restrict__ xhh, int *err, int tp, int nbp,
-             const double *__restrict__ dxr, const double *__restrict__ dxw, TanGeom g, int tt, int first,
-             const double *__restrict__ dsIn, double *__restrict__ dsOut, double *__restrict__ dpol) {
-    __shared__ double dVsh[RG][16 * 64];
+             const VT *__restrict__ dxr, const VT *__restrict__ dxw, TanGeom g, int tt, int first,
+             const VT *__restrict__ dsIn, VT *__restrict__ dsOut, VT *__restrict__ dpol) {
+    __shared__ VT dVsh[RG][16 * 64];
     __shared__ double Pish[256];
     if ((int)blockIdx.x < nbp) {
         if (blockIdx.y != 0 || tp < 0 || (int)threadIdx.x >= RBP * c.n_e) return;
-        egm_step_body(c, R, xhh, tp, err, blockIdx.x, &dVsh[0][0]);   // needs n_e*RBP + n_e^2 <= 768 doubles
+        egm_step_body(c, R, xhh, tp, err, blockIdx.x, reinterpret_cast<double *>(&dVsh[0][0]));   // needs n_e*RBP + n_e^2 <= 768 doubles
         return;
     }
     if (tt < 0) return;
-    tan_back_body<RG>(c, R, xhh, dxr, dxw, g, tt, first, dsIn, dsOut, dpol, blockIdx.x - nbp, blockIdx.y, dVsh, Pish);
+    tan_back_body<RG, VT>(c, R, xhh, dxr, dxw, g, tt, first, dsIn, dsOut, dpol, blockIdx.x - nbp, blockIdx.y, dVsh, Pish);
 }
 
 // one forward period: segment gather of the lottery tangent (ForwardIteration.jl:37-99 under
@@ -562,9 +596,9 @@ k_fused_back(Consts c, Record R, const double *__restrict__ xhh, int *err, int t
 //     0's tangent is (real row 0) + sum_p (virtual row p). Everything downstream is linear, so the
 //     parts are never combined: a virtual row is a source with row 0's lottery (no own policy
 //     tangent), and its aggregate term uses pol[0, e].
-template <int RG>
-__device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanGeom &g, int t, const double *__restrict__ dDin, double *__restrict__ dDout,
-          const double *__restrict__ dpol, double *__restrict__ aggpart, int bidx, int bidy, int nbx_total, double (*sh)[16 * 64], double *Pish) {
+template <int RG, typename VT>
+__device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanGeom &g, int t, const VT *__restrict__ dDin, VT *__restrict__ dDout,
+          const VT *__restrict__ dpol, VT *__restrict__ aggpart, int bidx, int bidy, int nbx_total, VT (*sh)[16 * 64], double *Pish) {
     const int nthr = 64 * c.n_e;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
@@ -574,16 +608,18 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
     const int na = c.n_a, nav = c.n_a + KV;
     const size_t base = (size_t)t * c.G, cb = base + (size_t)e * na;
     const double *Dnew = R.Dseq + base + c.G + (size_t)e * na;
-    const double *dDc = dDin + ((size_t)e * nav) * N + n;
-    const double *dpc = dpol + cb * N + n;
+    const VT *dDc = dDin + ((size_t)e * nav) * N + n;
+    const VT *dpc = dpol + cb * N + n;
     const int clo = R.clo[(size_t)t * c.n_e + e];
     const int nbr = (g.nbx + RG - 1) / RG;            // regular blocks
     const bool virt_block = bidx >= nbr;
     const bool nok = n < g.N;
     int r[RG];
     bool valid[RG];
-    double acc[RG], cp[RG];
-    double pagg = 0.0;    // sum of dpol_j * D_t[j] over the sources this thread owns
+    VT acc[RG];
+    double cp[RG];
+    VT pagg;              // sum of dpol_j * D_t[j] over the sources this thread owns
+    vzero(pagg);
     if (!virt_block) {
         int s0[RG], s1[RG], s2[RG];
 #pragma unroll
@@ -599,26 +635,28 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
         }
 #pragma unroll
         for (int q = 0; q < RG; q++) {
-            double s = 0.0;
+            VT s;
+            vzero(s);
             if (valid[q]) {
                 for (int j = s0[q]; j < s1[q]; j++) {
                     // every unclamped source sits in exactly one FIRST segment: its aggregate term
                     // dpol_j * D_t[j] is taken here, so dpol is not read a third time by its own row
-                    const double dpj = dpc[(size_t)j * N];
+                    const VT dpj = dpc[(size_t)j * N];
                     const double2 wg = R.lwg[cb + j];
-                    s += wg.x * dDc[(size_t)j * N] + dpj * wg.y;
-                    pagg += dpj * Dnew[j];
+                    s = vadd(s, vadd(vmul(wg.x, dDc[(size_t)j * N]), vmul(wg.y, dpj)));
+                    pagg = vadd(pagg, vmul(Dnew[j], dpj));
                 }
                 for (int j = s1[q]; j < s2[q]; j++) {
                     const double2 wg = R.lwg[cb + j];
-                    s += (1.0 - wg.x) * dDc[(size_t)j * N] - dpc[(size_t)j * N] * wg.y;
+                    s = vadd(s, vsub(vmul(1.0 - wg.x, dDc[(size_t)j * N]), vmul(wg.y, dpc[(size_t)j * N])));
                 }
                 // row 0 not clamped: its virtual rows follow row 0's (interior) lottery
                 if (clo == 0 && s2[q] > 0 && (s0[q] == 0 || s1[q] == 0)) {
                     const double w0 = (s0[q] == 0 && s1[q] > 0) ? R.lw[cb] : 1.0 - R.lw[cb];
-                    double v = 0.0;
-                    for (int k = 0; k < KV; k++) v += dDc[(size_t)(na + k) * N];
-                    s += w0 * v;
+                    VT v;
+                    vzero(v);
+                    for (int k = 0; k < KV; k++) v = vadd(v, dDc[(size_t)(na + k) * N]);
+                    s = vadd(s, vmul(w0, v));
                 }
             }
             acc[q] = s;
@@ -626,72 +664,74 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
     } else {
         const int p = bidx - nbr;
 #pragma unroll
-        for (int q = 0; q < RG; q++) { r[q] = na + p; valid[q] = (q == 0) && nok && (rl == 0); acc[q] = 0.0; cp[q] = 0.0; }
+        for (int q = 0; q < RG; q++) { r[q] = na + p; valid[q] = (q == 0) && nok && (rl == 0); vzero(acc[q]); cp[q] = 0.0; }
         cp[0] = R.pol[cb];       // a virtual row carries row 0's policy and no policy tangent of its own
-        double s = 0.0;
+        VT s;
+        vzero(s);
         if (nok && clo > 0) {
             const int M = clo + KV;                         // clamped sources, then the virtual rows
             const int lo = (int)(((long long)M * p) / KV), hi = (int)(((long long)M * (p + 1)) / KV);
             for (int i = lo + rl; i < hi; i += RB) {
-                s += dDc[(size_t)(i < clo ? i : na + (i - clo)) * N];
-                if (i < clo) pagg += dpc[(size_t)i * N] * Dnew[i];   // clamped sources: policy partial is 0 except on a knot tie
+                s = vadd(s, dDc[(size_t)(i < clo ? i : na + (i - clo)) * N]);
+                if (i < clo) pagg = vadd(pagg, vmul(Dnew[i], dpc[(size_t)i * N]));   // clamped sources: policy partial is 0 except on a knot tie
             }
         }
-        for (int off = 32; off >= g.NC; off >>= 1) { s += __shfl_xor(s, off, 64); pagg += __shfl_xor(pagg, off, 64); }
-        if (rl != 0) pagg = 0.0;
+        for (int off = 32; off >= g.NC; off >>= 1) { s = vadd(s, vshfl_xor(s, off)); pagg = vadd(pagg, vshfl_xor(pagg, off)); }
+        if (rl != 0) vzero(pagg);
         acc[0] = s;
     }
     for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
 #pragma unroll
     for (int q = 0; q < RG; q++) sh[q][e * 64 + lane] = acc[q];
     __syncthreads();
-    double part = 0.0;
+    VT part;
+    vzero(part);
 #pragma unroll
     for (int q = 0; q < RG; q++) {
         if (valid[q]) {
-            double dDn = sh[q][lane] * Pish[c.n_e * e];      // dD_t[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
-            for (int k = 1; k < c.n_e; k++) dDn += sh[q][k * 64 + lane] * Pish[k + c.n_e * e];
+            VT dDn = vmul(Pish[c.n_e * e], sh[q][lane]);      // dD_t[r,e] = sum_k dD_mid[r,k] * Pi[k,e]
+            for (int k = 1; k < c.n_e; k++) dDn = vadd(dDn, vmul(Pish[k + c.n_e * e], sh[q][k * 64 + lane]));
             st_mode<HANK_ST_STATE>(&dDout[((size_t)e * nav + r[q]) * N + n], dDn);
-            part += cp[q] * dDn;
+            part = vadd(part, vmul(cp[q], dDn));
         }
     }
-    part += pagg;
+    part = vadd(part, pagg);
     __syncthreads();
     sh[0][e * 64 + lane] = part;
     __syncthreads();
     if (e == 0) {   // sum over columns, then over the RB row lanes of each tangent
-        double s = sh[0][lane];
-        for (int k = 1; k < c.n_e; k++) s += sh[0][k * 64 + lane];
-        for (int off = 32; off >= g.NC; off >>= 1) s += __shfl_xor(s, off, 64);
+        VT s = sh[0][lane];
+        for (int k = 1; k < c.n_e; k++) s = vadd(s, sh[0][k * 64 + lane]);
+        for (int off = 32; off >= g.NC; off >>= 1) s = vadd(s, vshfl_xor(s, off));
         if (rl == 0 && nok) aggpart[((size_t)t * nbx_total + bidx) * N + n] = s;
     }
 }
 
-template <int RG>
+template <int RG, typename VT>
 __global__ void __launch_bounds__(1024)
-k_tan_fwd(Consts c, Record R, TanGeom g, int t, const double *__restrict__ dDin, double *__restrict__ dDout,
-          const double *__restrict__ dpol, double *__restrict__ aggpart) {
-    __shared__ double sh[RG][16 * 64];
+k_tan_fwd(Consts c, Record R, TanGeom g, int t, const VT *__restrict__ dDin, VT *__restrict__ dDout,
+          const VT *__restrict__ dpol, VT *__restrict__ aggpart) {
+    __shared__ VT sh[RG][16 * 64];
     __shared__ double Pish[256];
-    tan_fwd_body<RG>(c, R, g, t, dDin, dDout, dpol, aggpart, blockIdx.x, blockIdx.y, gridDim.x, sh, Pish);
+    tan_fwd_body<RG, VT>(c, R, g, t, dDin, dDout, dpol, aggpart, blockIdx.x, blockIdx.y, gridDim.x, sh, Pish);
 }
 
 // the dual-sweep forward launch: blocks [0, nbp) of grid row 0 run the PRIMAL distribution step of
 // period tp, the others the tangent step of period tt = tp - 1 (D_{tt+1} was written by the previous launch).
-template <int RG>
+template <int RG, typename VT>
 __global__ void __launch_bounds__(1024)
 k_fused_fwd(Consts c, Record R, int tp, int nbp, double *__restrict__ paggpart, TanGeom g, int tt,
-            const double *__restrict__ dDin, double *__restrict__ dDout, const double *__restrict__ dpol,
-            double *__restrict__ aggpart) {
-    __shared__ double sh[RG][16 * 64];
+            const VT *__restrict__ dDin, VT *__restrict__ dDout, const VT *__restrict__ dpol,
+            VT *__restrict__ aggpart) {
+    __shared__ VT sh[RG][16 * 64];
     __shared__ double Pish[256];
     if ((int)blockIdx.x < nbp) {
         if (blockIdx.y != 0 || tp < 0 || (int)threadIdx.x >= RBP * c.n_e) return;
-        dist_step_body(c, R, tp, paggpart, blockIdx.x, nbp, &sh[0][0]);
+        dist_step_body(c, R, tp, paggpart, blockIdx.x, nbp, reinterpret_cast<double *>(&sh[0][0]));
         return;
     }
     if (tt < 0) return;
-    tan_fwd_body<RG>(c, R, g, tt, dDin, dDout, dpol, aggpart, blockIdx.x - nbp, blockIdx.y, gridDim.x - nbp, sh, Pish);
+    tan_fwd_body<RG, VT>(c, R, g, tt, dDin, dDout, dpol, aggpart, blockIdx.x - nbp, blockIdx.y, gridDim.x - nbp, sh, Pish);
 }
 
 // ---- granular tangent halves (hank_backward_step_dual) ---------------------------------------
