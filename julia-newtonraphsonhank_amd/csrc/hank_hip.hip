@@ -15,13 +15,17 @@
 
 using namespace hank;
 
-// wealth-row groups per wave: the backward kernel's gathers are independent, so 2 groups per wave keep
-// twice the bytes in flight (1 / 2 / 4 groups: dual backward sweep 3.61 / 3.12 / 3.32 ms at N=32,
-// 16.3 / 12.6 / 14.8 ms at N=256; 4 was best before the coefficient loads went lane-sparse);
-// the forward kernel's segment loops are serial per row and prefer more, shorter waves — one group
-// per wave up to N = 64, two from N = 128 on (forward sweep 20.8 -> 18.5 ms at N = 256; 3.7 -> 4.0 ms at N = 32).
-constexpr int TAN_RG = 2;
-static inline int tan_rgf(int NV) { return NV >= 128 ? 2 : 1; }   // NV = lanes' worth of directions
+// Lane geometry of the tangent kernels, chosen per batch width N (measured, MI355X, 2000x11, T=300):
+//  - lane width: an even batch runs TWO adjacent directions per lane (double2): every state / dpol access is
+//    16 bytes, half the vector-memory instructions per byte (N=32: 4650 -> 5380 JVPs/s; N=256: 8130 -> 10940);
+//  - wealth-row groups per wave: backward 2 (4 from 256 directions on) — its gathers are independent, more
+//    groups = more bytes in flight per wave; forward 1 at N=32, 2 from N=64 on — its segment loops are serial
+//    per row and the small batch prefers more, shorter waves.
+static inline int tan_rg(int NV, int forward) {   // NV = lanes' worth of directions
+    const char *e = getenv(forward ? "HANK_RG_F" : "HANK_RG_B");   // dev knobs
+    if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
+    return forward ? (NV >= 32 ? 2 : 1) : (NV >= 128 ? 4 : 2);
+}
 static inline int tan_lane_width(int N, int forward) {
     const char *e = getenv(forward ? "HANK_LANE_WIDTH_F" : "HANK_LANE_WIDTH_B");   // dev knobs
     const int want = e ? atoi(e) : 2;
@@ -153,8 +157,16 @@ static int build_primal_graphs(hank_ctx *ctx) {
 }
 
 // Captures the four tangent graphs for lane type VT (double: one direction per lane; double2: two).
+// the row-group count is a template parameter of the kernels and a run-time choice here
+#define LAUNCH_RG(RGV, KERNEL, VTYPE, ...)                                                      \
+    do {                                                                                        \
+        if ((RGV) == 4) hipLaunchKernelGGL((KERNEL<4, VTYPE>), __VA_ARGS__);                    \
+        else if ((RGV) == 2) hipLaunchKernelGGL((KERNEL<2, VTYPE>), __VA_ARGS__);               \
+        else hipLaunchKernelGGL((KERNEL<1, VTYPE>), __VA_ARGS__);                               \
+    } while (0)
+
 template <typename VT, typename VF>
-static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGF, unsigned nbf) {
+static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, unsigned nbf) {
     const Consts &c = ctx->c;
     const size_t P = c.P;
     const int N = w.N;
@@ -168,15 +180,15 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGF, unsigned n
     VF *dD[2] = {reinterpret_cast<VF *>(w.dD[0]), reinterpret_cast<VF *>(w.dD[1])};
     VT *dpol = reinterpret_cast<VT *>(w.dpol);
     VF *dpolf = reinterpret_cast<VF *>(w.dpol), *aggpart = reinterpret_cast<VF *>(w.aggpart);
-    const unsigned nbt = (w.nbx + TAN_RG - 1) / TAN_RG;
+    const unsigned nbt = (w.nbx + RGB - 1) / RGB;
     // backward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    hipLaunchKernelGGL((k_tan_back<TAN_RG, VT>), dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, w.g, (int)P - 1, 1,
+    LAUNCH_RG(RGB, k_tan_back, VT, dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, w.g, (int)P - 1, 1,
                        ds[1], ds[0], dpol);
     int cur = 0;
     for (int t = (int)P - 1; t >= 0; t--) {
-        hipLaunchKernelGGL((k_tan_back<TAN_RG, VT>), dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, w.g, t, 0,
+        LAUNCH_RG(RGB, k_tan_back, VT, dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, w.g, t, 0,
                            ds[cur], ds[cur ^ 1], dpol);
         cur ^= 1;
     }
@@ -187,8 +199,7 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGF, unsigned n
     hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
     cur = 0;
     for (int t = 0; t < (int)P; t++) {
-        if (RGF == 2) hipLaunchKernelGGL((k_tan_fwd<2, VF>), dim3(nbf, nyf), blk, 0, s, c, ctx->R, w.gf, t, dD[cur], dD[cur ^ 1], dpolf, aggpart);
-        else hipLaunchKernelGGL((k_tan_fwd<1, VF>), dim3(nbf, nyf), blk, 0, s, c, ctx->R, w.gf, t, dD[cur], dD[cur ^ 1], dpolf, aggpart);
+        LAUNCH_RG(RGF, k_tan_fwd, VF, dim3(nbf, nyf), blk, 0, s, c, ctx->R, w.gf, t, dD[cur], dD[cur ^ 1], dpolf, aggpart);
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
@@ -212,10 +223,10 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGF, unsigned n
     for (int k = 0; k <= (int)P; k++) {
         const int tp = k < (int)P ? (int)P - 1 - k : -1;
         if (k == 0) {
-            hipLaunchKernelGGL((k_fused_back<TAN_RG, VT>), dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
+            LAUNCH_RG(RGB, k_fused_back, VT, dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
                                dxr, dxw, w.g, (int)P - 1, 1, ds[1], ds[0], dpol);
         } else {
-            hipLaunchKernelGGL((k_fused_back<TAN_RG, VT>), dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
+            LAUNCH_RG(RGB, k_fused_back, VT, dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
                                dxr, dxw, w.g, (int)P - k, 0, ds[cur], ds[cur ^ 1], dpol);
             cur ^= 1;
         }
@@ -228,10 +239,8 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGF, unsigned n
     cur = 0;
     for (int k = 0; k <= (int)P; k++) {
         const int tp = k < (int)P ? k : -1, tt = k - 1;
-        if (RGF == 2) hipLaunchKernelGGL((k_fused_fwd<2, VF>), dim3(ctx->nbp + nbf, nyf), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.gf, tt,
-                                         dD[cur], dD[cur ^ 1], dpolf, aggpart);
-        else hipLaunchKernelGGL((k_fused_fwd<1, VF>), dim3(ctx->nbp + nbf, nyf), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.gf, tt,
-                                dD[cur], dD[cur ^ 1], dpolf, aggpart);
+        LAUNCH_RG(RGF, k_fused_fwd, VF, dim3(ctx->nbp + nbf, nyf), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.gf, tt,
+                  dD[cur], dD[cur ^ 1], dpolf, aggpart);
         if (tt >= 0) cur ^= 1;
     }
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
@@ -271,13 +280,13 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
         HIPC(ctx, dmalloc(&w.dD[k], GV * N));
     }
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-    const int RGF = tan_rgf(w.gf.N);
+    const int RGB = tan_rg(w.g.N, 0), RGF = tan_rg(w.gf.N, 1);
     const unsigned nbf = (w.nbxf + RGF - 1) / RGF + KV;   // forward blocks: regular + mass-point
     HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
-    if (VB == 2) return VF == 2 ? capture_tangent_graphs<double2, double2>(ctx, w, RGF, nbf) : capture_tangent_graphs<double2, double>(ctx, w, RGF, nbf);
-    return VF == 2 ? capture_tangent_graphs<double, double2>(ctx, w, RGF, nbf) : capture_tangent_graphs<double, double>(ctx, w, RGF, nbf);
+    if (VB == 2) return VF == 2 ? capture_tangent_graphs<double2, double2>(ctx, w, RGB, RGF, nbf) : capture_tangent_graphs<double2, double>(ctx, w, RGB, RGF, nbf);
+    return VF == 2 ? capture_tangent_graphs<double, double2>(ctx, w, RGB, RGF, nbf) : capture_tangent_graphs<double, double>(ctx, w, RGB, RGF, nbf);
 }
 
 static int fetch_device_error(hank_ctx *ctx) {
