@@ -85,24 +85,44 @@ def extra_measurements(hb, d_x, P, N, dev):
         except Exception as e:          # noqa: BLE001 - report, do not kill the bench line
             res = {"grid": "500x4", "T": 300, "shock": shock, "error": str(e)[:200]}
         extra["converged_path"].append(res)
-    # wider batch on the same context (same primal): N = 256 tangents in one hank_jvp
+    # wider batch on the same context: N = 256 tangents in one dual-sweep pass
     Nw = 256
     d_dx = torch.randn(2 * P * Nw, dtype=torch.float64, device=dev)
     d_out = torch.empty(P * Nw, dtype=torch.float64, device=dev)
-    hb.jvp_dev(d_dx.data_ptr(), Nw, d_out.data_ptr())
-    torch.cuda.synchronize()
+    d_agg = torch.empty(P, dtype=torch.float64, device=dev)
+    hb.primal_jvp_dev(d_x.data_ptr(), d_dx.data_ptr(), Nw, d_agg.data_ptr(), d_out.data_ptr())
+    hb.sync()
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
-        hb.primal_dev(d_x.data_ptr(), 0)
-        hb.jvp_dev(d_dx.data_ptr(), Nw, d_out.data_ptr())
-    torch.cuda.synchronize()
+        hb.primal_jvp_dev(d_x.data_ptr(), d_dx.data_ptr(), Nw, d_agg.data_ptr(), d_out.data_ptr())
+    hb.sync()
     el = (time.perf_counter() - t0) / reps
     tm = hb.last_timings()
     G8 = hb.G * 8
     extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el,
-                           "k_tan_back_GBs": G8 * Nw / (1e-3 * tm["tangent_backward"]["ms"] / tm["tangent_backward"]["launches"]) / 1e9,
-                           "k_tan_fwd_GBs": G8 * Nw / (1e-3 * tm["tangent_forward"]["ms"] / tm["tangent_forward"]["launches"]) / 1e9}
+                           "k_fused_back_GBs": G8 * (1 + Nw) / (1e-3 * tm["dual_backward"]["ms"] / tm["dual_backward"]["launches"]) / 1e9,
+                           "k_fused_fwd_GBs": G8 * (1 + Nw) / (1e-3 * tm["dual_forward"]["ms"] / tm["dual_forward"]["launches"]) / 1e9}
+    # two independent N-wide batches in flight (two contexts, two streams): what a Jacobian assembly, whose column
+    # batches do not depend on each other, gets out of the latency-bound per-period launches
+    hb.jvp_dev(d_dx.data_ptr(), N, d_out.data_ptr())   # shrink the first context's workspace back to N
+    hb2 = hb.clone()
+    try:
+        bufs = [(torch.randn(2 * P * N, dtype=torch.float64, device=dev), torch.empty(P, dtype=torch.float64, device=dev),
+                 torch.empty(P * N, dtype=torch.float64, device=dev)) for _ in range(2)]
+        def both():
+            for h_, (dx_, ag_, out_) in zip((hb, hb2), bufs):
+                h_.primal_jvp_dev(d_x.data_ptr(), dx_.data_ptr(), N, ag_.data_ptr(), out_.data_ptr())
+        both(); hb.sync(); hb2.sync()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            both()
+        hb.sync(); hb2.sync()
+        el = (time.perf_counter() - t0) / reps
+        extra["two_batches_in_flight"] = {"tangents": 2 * N, "JVPs_per_s": 2 * N / el, "ms_per_pair": 1e3 * el}
+    finally:
+        hb2.close()
     return extra
 
 

@@ -132,6 +132,8 @@ class HouseholdBlock:
         self.n_a, self.n_e = self.a_grid.size, self.z_grid.size
         self.Pi = _f(Pi, (self.n_e, self.n_e))
         self.T, self.P, self.G = int(T), int(T) - 1, self.n_a * self.n_e
+        self._params = (float(beta), float(gamma), float(borrow_cons), value_fn_id)
+        self._boundary = None
         m = hank_model(self.n_a, self.n_e, self.T, value_fn_id, _p(self.a_grid), _p(self.z_grid),
                        _p(self.Pi), float(beta), float(gamma), float(borrow_cons))
         rc = self._lib.hank_create(C.byref(m), C.byref(self._ctx))
@@ -149,6 +151,15 @@ class HouseholdBlock:
     def _chk(self, rc: int):
         if rc != HANK_OK:
             raise _ERR_CLASSES.get(rc, HankHIPError)(rc, self._lib.hank_last_error(self._ctx).decode())
+
+    def clone(self) -> "HouseholdBlock":
+        """A second, independent context of the same model and boundary (its own device memory, graphs and
+        stream): independent tangent batches — Jacobian column chunks — can be in flight on both."""
+        beta, gamma, bc, vf = self._params
+        other = HouseholdBlock(self.a_grid, self.z_grid, self.Pi, beta, gamma, bc, self.T, vf)
+        if self._boundary is not None:
+            other.set_boundary(*self._boundary)
+        return other
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -175,6 +186,7 @@ class HouseholdBlock:
         v = _f(ss_end_value, (self.n_a, self.n_e))
         d = _f(np.asarray(ss_init_D, dtype=np.float64).reshape((self.n_a, self.n_e), order="F"))
         self._chk(self._lib.hank_set_boundary(self._ctx, _p(v), _p(d)))
+        self._boundary = (v, d)
 
     def primal(self, xhh) -> np.ndarray:
         x = _f(xhh, (self.n_hh, self.P))
