@@ -19,12 +19,12 @@ using namespace hank;
 //  - lane width: an even batch runs TWO adjacent directions per lane (double2): every state / dpol access is
 //    16 bytes, half the vector-memory instructions per byte (N=32: 4650 -> 5380 JVPs/s; N=256: 8130 -> 10940);
 //  - wealth-row groups per wave: backward 2 (4 from 256 directions on) — its gathers are independent, more
-//    groups = more bytes in flight per wave; forward 1 at N=32, 2 from N=64 on — its segment loops are serial
-//    per row and the small batch prefers more, shorter waves.
-static inline int tan_rg(int NV, int forward) {   // NV = lanes' worth of directions
+//    groups = more bytes in flight per wave; forward 2 for 16-lane groups (N = 18..32, which run the
+//    source-stationary form of the forward kernel, see ensure_tanwork) and from N = 64 on, 1 otherwise.
+static inline int tan_rg(int NV, int forward, int ss = 0) {   // NV = lanes' worth of directions
     const char *e = getenv(forward ? "HANK_RG_F" : "HANK_RG_B");   // dev knobs
     if (e) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
-    return forward ? (NV >= 32 ? 2 : 1) : (NV >= 128 ? 4 : 2);
+    return forward ? ((NV >= 32 || ss) ? 2 : 1) : (NV >= 128 ? 4 : 2);
 }
 static inline int tan_lane_width(int N, int forward) {
     const char *e = getenv(forward ? "HANK_LANE_WIDTH_F" : "HANK_LANE_WIDTH_B");   // dev knobs
@@ -165,6 +165,19 @@ static int build_primal_graphs(hank_ctx *ctx) {
         else hipLaunchKernelGGL((KERNEL<1, VTYPE>), __VA_ARGS__);                               \
     } while (0)
 
+#define LAUNCH_RG_SS(RGV, SSV, KERNEL, VTYPE, ...)                                              \
+    do {                                                                                        \
+        if (SSV) {                                                                              \
+            if ((RGV) == 4) hipLaunchKernelGGL((KERNEL<4, VTYPE, true>), __VA_ARGS__);          \
+            else if ((RGV) == 2) hipLaunchKernelGGL((KERNEL<2, VTYPE, true>), __VA_ARGS__);     \
+            else hipLaunchKernelGGL((KERNEL<1, VTYPE, true>), __VA_ARGS__);                     \
+        } else {                                                                                \
+            if ((RGV) == 4) hipLaunchKernelGGL((KERNEL<4, VTYPE, false>), __VA_ARGS__);         \
+            else if ((RGV) == 2) hipLaunchKernelGGL((KERNEL<2, VTYPE, false>), __VA_ARGS__);    \
+            else hipLaunchKernelGGL((KERNEL<1, VTYPE, false>), __VA_ARGS__);                    \
+        }                                                                                       \
+    } while (0)
+
 template <typename VT, typename VF>
 static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, unsigned nbf) {
     const Consts &c = ctx->c;
@@ -199,7 +212,7 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
     hipLaunchKernelGGL(k_zero_f64, dim3(512), dim3(256), 0, s, w.dD[0], GV * N);  // dD_0 = 0 (ForwardIteration.jl:293)
     cur = 0;
     for (int t = 0; t < (int)P; t++) {
-        LAUNCH_RG(RGF, k_tan_fwd, VF, dim3(nbf, nyf), blk, 0, s, c, ctx->R, w.gf, t, dD[cur], dD[cur ^ 1], dpolf, aggpart);
+        LAUNCH_RG_SS(RGF, w.gf.ss, k_tan_fwd, VF, dim3(nbf, nyf), blk, 0, s, c, ctx->R, w.gf, t, dD[cur], dD[cur ^ 1], dpolf, aggpart);
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
@@ -239,7 +252,7 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
     cur = 0;
     for (int k = 0; k <= (int)P; k++) {
         const int tp = k < (int)P ? k : -1, tt = k - 1;
-        LAUNCH_RG(RGF, k_fused_fwd, VF, dim3(ctx->nbp + nbf, nyf), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.gf, tt,
+        LAUNCH_RG_SS(RGF, w.gf.ss, k_fused_fwd, VF, dim3(ctx->nbp + nbf, nyf), blk, 0, s, c, ctx->R, tp, ctx->nbp, ctx->d_aggpart, w.gf, tt,
                   dD[cur], dD[cur ^ 1], dpolf, aggpart);
         if (tt >= 0) cur ^= 1;
     }
@@ -268,6 +281,7 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
         while (NC < NV && NC < 64) { NC <<= 1; lg++; }
         const int RB = 64 / NC;
         g.N = NV; g.NC = NC; g.lgNC = lg; g.nbx = (c.n_a + RB - 1) / RB;
+        g.ss = 0;
     };
     geom(VB, w.g); geom(VF, w.gf);
     w.nbx = w.g.nbx; w.nbxf = w.gf.nbx;
@@ -280,7 +294,11 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
         HIPC(ctx, dmalloc(&w.dD[k], GV * N));
     }
     HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-    const int RGB = tan_rg(w.g.N, 0), RGF = tan_rg(w.gf.N, 1);
+    // forward kernel form: source-stationary for 16-lane groups (N = 18..32: forward sweep 3.42 -> 3.05 ms at N=32
+    // with 2 row groups), target-stationary gather otherwise (equal within 2 % at N = 16, 64, 256)
+    const char *se = getenv("HANK_FWD_SS");   // dev knob
+    w.gf.ss = se ? atoi(se) : (w.gf.NC == 16 ? 1 : 0);
+    const int RGB = tan_rg(w.g.N, 0), RGF = tan_rg(w.gf.N, 1, w.gf.ss);
     const unsigned nbf = (w.nbxf + RGF - 1) / RGF + KV;   // forward blocks: regular + mass-point
     HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
