@@ -76,12 +76,14 @@ end
 function _run_block(ctx::HankCtx, value, D0, xhh, dxhh)
     _check(ctx.ptr, ccall((:hank_set_boundary, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, value, D0))
     agg = Vector{Float64}(undef, ctx.P)
-    _check(ctx.ptr, ccall((:hank_primal, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, xhh, agg))
     dagg = nothing
-    if dxhh !== nothing
+    if dxhh === nothing
+        _check(ctx.ptr, ccall((:hank_primal, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, xhh, agg))
+    else      # a Dual pass carries value and partials together (NewtonRaphson.jl:95): one dual-sweep call
         N = size(dxhh, 3)
         dagg = Matrix{Float64}(undef, ctx.P, N)
-        _check(ctx.ptr, ccall((:hank_jvp, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}), ctx.ptr, dxhh, N, dagg))
+        _check(ctx.ptr, ccall((:hank_primal_jvp, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}),
+                              ctx.ptr, xhh, dxhh, N, agg, dagg))
     end
     return agg, dagg
 end
