@@ -97,11 +97,12 @@ def extra_measurements(hb, d_x, P, N, dev):
     import torch
     from examples.solve_transition import solve
     extra = {"converged_path": []}
-    for shock in (0.01, 0.8):          # mild shock, and RunMain.jl's Z_t = 1 + 0.8^t
+    # configs[1]'s grid with a mild shock and with RunMain.jl's Z_t = 1 + 0.8^t, then the headline grid
+    for n_a, n_e, shock in ((500, 4, 0.01), (500, 4, 0.8), (2000, 11, 0.01)):
         try:
-            res, _ = solve(500, 4, 300, shock)
+            res, _ = solve(n_a, n_e, 300, shock)
         except Exception as e:          # noqa: BLE001 - report, do not kill the bench line
-            res = {"grid": "500x4", "T": 300, "shock": shock, "error": str(e)[:200]}
+            res = {"grid": f"{n_a}x{n_e}", "T": 300, "shock": shock, "error": str(e)[:200]}
         extra["converged_path"].append(res)
     # wider batch on the same context: N = 256 tangents in one dual-sweep pass
     Nw = 256

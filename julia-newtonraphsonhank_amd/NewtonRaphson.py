@@ -47,12 +47,27 @@ class LinearizedFunction:
         self.Fx = Residuals(assemble_full_xMat(self.x, {k: self.agg for k in het}, exog_paths, mod,
                                                ss_initial, ss_ending), mod)
 
-    def jvp(self, y):
+    def jvp(self, y, pad_to: int | None = None):
+        """J(x)·y for one tangent (n,) or a batch (n, N). Directions that do not move the household inputs
+        (unit tangents in Y or KS, say) are not sent to the GPU — their household partials are zero; `pad_to`
+        rounds the device batch up to a multiple (zero columns) so that repeated calls reuse one workspace."""
         y = np.asarray(y, dtype=np.float64)
         single = y.ndim == 1
         xd = Dual.seed(self.x, y[:, None] if single else y)
         _, dxhh = household_inputs(xd, self.exog_paths, self.mod)
-        dagg = self.hb.jvp(dxhh)
+        dxhh = np.asarray(dxhh, dtype=np.float64)
+        if dxhh.ndim == 2:
+            dxhh = dxhh[:, :, None]
+        N = dxhh.shape[2]
+        nz = np.flatnonzero(np.any(dxhh != 0.0, axis=(0, 1)))
+        dagg = np.zeros((dxhh.shape[1], N))
+        if len(nz):
+            sub = dxhh[:, :, nz]
+            if pad_to and len(nz) % pad_to:
+                padded = np.zeros(sub.shape[:2] + (-(-len(nz) // pad_to) * pad_to,))
+                padded[:, :, :len(nz)] = sub
+                sub = padded
+            dagg[:, nz] = self.hb.jvp(sub)[:, :len(nz)]
         agg = {k: Dual(self.agg, dagg) for k in self.het}
         res = Residuals(assemble_full_xMat(xd, agg, self.exog_paths, self.mod, self.ss_initial, self.ss_ending), self.mod)
         return res.p[:, 0].copy() if single else res.p.copy()

@@ -16,8 +16,10 @@ from .GeneralStructures import SequenceModel, vars_of_type
 from .NewtonRaphson import LinearizedFunction
 
 
-def getSteadyStateJacobian(ss, model: SequenceModel, chunk: int = 256, drop_tol: float = 0.0):
-    """n x n sparse Jacobian of F at the constant steady-state path (SteadyStateJacobian.jl:41-65)."""
+def getSteadyStateJacobian(ss, model: SequenceModel, chunk: int = 512, drop_tol: float = 0.0, device_batch: int = 256):
+    """n x n sparse Jacobian of F at the constant steady-state path (SteadyStateJacobian.jl:41-65).
+    `chunk` unit tangents are pushed per call; only those that move the household inputs (r, w) reach the GPU,
+    in device batches padded to `device_batch` so that one tangent workspace serves every call."""
     cs = model.compspec
     if len(model.equations) != cs.n_endog:
         raise AssertionError(f"System is not square: {len(model.equations)} equations but {cs.n_endog} endogenous "
@@ -34,7 +36,7 @@ def getSteadyStateJacobian(ss, model: SequenceModel, chunk: int = 256, drop_tol:
         c1 = min(n, c0 + chunk)
         E = np.zeros((n, c1 - c0))
         E[np.arange(c0, c1), np.arange(c1 - c0)] = 1.0
-        J[:, c0:c1] = lin.jvp(E)
+        J[:, c0:c1] = lin.jvp(E, pad_to=device_batch)
     if drop_tol > 0:
         J[np.abs(J) < drop_tol] = 0.0
     return sp.csc_matrix(J)
