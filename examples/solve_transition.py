@@ -44,13 +44,44 @@ def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False):
             "wall_to_converged_path_s": round(t_jac + t_newton, 3)}, x
 
 
+def solve_permanent(n_a=200, n_e=3, T=150, Z_end=1.03, eps=1e-9, verbose=False):
+    """The two-steady-state scenario of the reference YAML (`ending:` block, KrusellSmith.yaml:109-116): TFP moves
+    to Z_end for good in period 1. The path starts from the initial steady state (KS_0, D_0 = ss_initial), the terminal
+    value is the ending steady state's (BackwardIteration.jl:85), Newton starts at the ending steady state repeated and
+    uses the sequence-space Jacobian there."""
+    import hank_amd as h
+    ov = {"T": T, "dimensions": {"wealth": {"n": n_a}, "productivity": {"n": n_e}},
+          "steady_states": {"ending": {"fixed": {"Z": Z_end}, "guesses": {"r": 0.04, "w": 1.0, "Y": 1.5, "KS": 3.5}}}}
+    m = h.build_model_from_yaml(str(ROOT / "examples" / "krusell_smith.yaml"), overrides=ov)
+    t0 = time.perf_counter()
+    ss_i, ss_e = h.get_SteadyStates(m)
+    t_ss = time.perf_counter() - t0
+    P = T - 1
+    Z = np.full(P, float(Z_end))
+    x0 = np.tile(np.array([ss_e.vars[k] for k in ("Y", "KS", "r", "w")]), P)
+    t0 = time.perf_counter()
+    J = h.getSteadyStateJacobian(ss_e, m)
+    x = h.NewtonRaphsonHANK(x0, J, {"Z": Z}, m, ss_i, ss_e, ε=eps, verbose=verbose)
+    t_solve = time.perf_counter() - t0
+    lin = h.LinearizedFunction(x, {"Z": Z}, m, ss_i, ss_e)
+    return {"grid": f"{n_a}x{n_e}", "T": T, "shock": f"Z: 1 -> {Z_end} for good", "steady_states_s": round(t_ss, 3),
+            "newton_iterations": h.NewtonRaphsonHANK.iterations, "residual_norm": float(np.linalg.norm(lin.Fx)),
+            "wall_to_converged_path_s": round(t_solve, 3), "KS_start": ss_i.vars["KS"], "KS_end": ss_e.vars["KS"],
+            "KS_path_first_last": [float(x.reshape(4, P, order="F")[1, 0]), float(x.reshape(4, P, order="F")[1, -1])]}, x, ss_i, ss_e
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-a", type=int, default=500)
     ap.add_argument("--n-e", type=int, default=4)
     ap.add_argument("--T", type=int, default=300)
     ap.add_argument("--shock", type=float, default=0.01)
+    ap.add_argument("--permanent", type=float, default=None, metavar="Z_END", help="two-steady-state scenario: Z jumps to Z_END for good")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
+    if a.permanent is not None:
+        out = solve_permanent(a.n_a, a.n_e, a.T, a.permanent, verbose=a.verbose)[0]
+        print(json.dumps(out))
+        sys.exit(0)
     out, x = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose)
     print(json.dumps(out))

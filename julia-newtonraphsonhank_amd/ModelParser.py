@@ -195,7 +195,8 @@ def build_model_from_yaml(file_path: str, overrides: dict | None = None) -> Sequ
     (e.g. KrusellSmith.jl -> the KrusellSmith module of this package) registers the native kernel
     family behind the YAML's `function: "ValueFunction"`.
     `overrides` (not in the reference) lets benchmarks resize a spec without editing the YAML:
-    {"T": 300, "dimensions": {"wealth": {"n": 2000}, "productivity": {"n": 11}}}."""
+    {"T": 300, "dimensions": {"wealth": {"n": 2000}, "productivity": {"n": 11}},
+     "steady_states": {"ending": {"fixed": {"Z": 1.03}, "guesses": {...}}}}  (adds / replaces steady-state blocks)."""
     with open(file_path, "r", encoding="utf-8") as fh:
         y = yaml.safe_load(fh)
     overrides = overrides or {}
@@ -242,7 +243,7 @@ def build_model_from_yaml(file_path: str, overrides: dict | None = None) -> Sequ
     residuals_fn = compile_residuals(equations, all_names, param_names)
     compspec = ComputationalSpec(T, ε, dx, len(variables), len(endog), max_lag, max_lead)
     # 5. steady states
-    ss = y["steady_states"]
+    ss = dict(y["steady_states"], **(overrides.get("steady_states") or {}))
     ss_initial = _parse_ss_spec(ss["initial"])
     ss_ending = _parse_ss_spec(ss["ending"]) if "ending" in ss else ss_initial
     return SequenceModel(variables, equations, compspec, params, residuals_fn, ss_initial, ss_ending,

@@ -82,3 +82,22 @@ def test_newton_converges_on_a_small_shock(hank):
     assert np.linalg.norm(lin.Fx) < 1e-8 < np.linalg.norm(lin0.Fx)
     F_o, _ = orc.ks_jvp(xs.reshape(4, P, order="F"), np.zeros((4, P, 1)), Z, m.params.α, m.params.δ, ss.vars["KS"], ss.value, ss.D)
     assert np.max(np.abs(F_o - lin.Fx)) < 1e-10
+
+
+def test_permanent_shock_between_two_steady_states(hank):
+    """the reference YAML's two-steady-state scenario (`ending:` block, KrusellSmith.yaml:109-116): terminal value from
+    the ENDING steady state, initial distribution and KS_0 from the INITIAL one (BackwardIteration.jl:85,
+    ForwardIteration.jl:293, GeneralStructures.jl:329-377); Newton converges and the path joins the two."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from examples.solve_transition import solve_permanent
+    out, x, ss_i, ss_e = solve_permanent(n_a=60, n_e=2, T=120, Z_end=1.02)
+    assert out["residual_norm"] < 1e-8
+    P = 119
+    KS = x.reshape(4, P, order="F")[1]
+    assert ss_e.vars["KS"] > ss_i.vars["KS"]
+    # capital starts near the old steady state, rises monotonically, ends at the new one
+    assert abs(KS[0] - ss_i.vars["KS"]) < 0.2 * (ss_e.vars["KS"] - ss_i.vars["KS"])
+    assert np.all(np.diff(KS) > -1e-9)
+    assert abs(KS[-1] - ss_e.vars["KS"]) < 2e-3 * ss_e.vars["KS"]
