@@ -12,7 +12,8 @@
  *     (GeneralStructures.jl:500-525; used as V'*Pi' backward, KrusellSmith.jl:59, and D*Pi forward,
  *     ForwardIteration.jl:280-284).
  *   - "xhh" are the per-period household inputs the value function reads from xVals; for the
- *     Krusell-Smith plugin that is (r_t, w_t) (KrusellSmith.jl:53-54): xhh[k + n_hh*t], n_hh = 2.
+ *     Krusell-Smith plugin that is (r_t, w_t) (KrusellSmith.jl:53-54): xhh[k + n_hh*t], n_hh = 2
+ *     (3 for the one-asset HANK family: (r_t, w_t, tr_t)); hank_n_hh() tells.
  *   - tangent batches are Julia-natural: dxhh is (n_hh, P, N) column-major, dagg is (P, N).
  *   - the caller owns every host buffer; the library copies in/out and retains no pointer past a
  *     call; the context owns all device memory. A context is bound to the HIP device that was
@@ -50,7 +51,11 @@ enum {
 
 /* value-function families resolved from the YAML `function:` name (KrusellSmith.yaml:86,
  * ModelParser.jl:338-342 / _lookup_fn :404-413). */
-enum { HANK_VF_KRUSELL_SMITH = 0 };
+enum {
+    HANK_VF_KRUSELL_SMITH = 0,  /* KrusellSmith.jl:43-83; household inputs (r_t, w_t)                                  */
+    HANK_VF_ONE_ASSET_HANK = 1  /* the same EGM step with a lump-sum transfer: inputs (r_t, w_t, tr_t), cash on hand
+                                   (1+r) a + w z_e + tr. NOT in the reference: parity unpinned     */
+};
 
 /* The model-side constants BackwardIteration/ForwardIteration read from `model::SequenceModel`
  * (GeneralStructures.jl:216-226): heterogeneity grids + params + compspec.T. */

@@ -36,7 +36,7 @@ struct TanWork {
     int N = 0;
     TanGeom g{}, gf{};   // lane geometry of the backward / forward tangent kernels
     double *dxhh = nullptr;   // (2,P,N) staging for the host-pointer entry
-    double *dxr = nullptr, *dxw = nullptr;
+    double *dxr = nullptr, *dxw = nullptr, *dxt = nullptr;   // [P][N] tangents of r, w (, lump-sum transfer)
     double *ds[2] = {nullptr, nullptr};
     double *dD[2] = {nullptr, nullptr};
     double *dpol = nullptr;
@@ -113,7 +113,7 @@ static void free_tanwork(TanWork &w) {
     if (w.g_fwd) (void)hipGraphExecDestroy(w.g_fwd);
     if (w.g_fback) (void)hipGraphExecDestroy(w.g_fback);
     if (w.g_ffwd) (void)hipGraphExecDestroy(w.g_ffwd);
-    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw);
+    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw); (void)hipFree(w.dxt);
     (void)hipFree(w.ds[0]); (void)hipFree(w.ds[1]); (void)hipFree(w.dD[0]); (void)hipFree(w.dD[1]);
     (void)hipFree(w.dpol); (void)hipFree(w.aggpart); (void)hipFree(w.dagg); (void)hipFree(w.dagg_cm);
     w = TanWork();
@@ -138,7 +138,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
     // backward: X of the last period from the terminal value, then P fused Y;X steps, then lottery
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
-    hipLaunchKernelGGL(k_egm_X, grd, blk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
+    hipLaunchKernelGGL(k_egm_X, grd, blk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + c.n_hh * (P - 1),
                        ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1);
     for (int t = P - 1; t >= 0; t--)
         hipLaunchKernelGGL(k_egm_step, grd, blk, lds, s, c, ctx->R, ctx->d_xhh, t, ctx->d_err);
@@ -188,7 +188,7 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
     const dim3 blk(64 * c.n_e);
     const unsigned ny = (w.g.N + w.g.NC - 1) / w.g.NC, nyf = (w.gf.N + w.gf.NC - 1) / w.gf.NC;
     const int PN = (int)(P * N);
-    const VT *dxr = reinterpret_cast<const VT *>(w.dxr), *dxw = reinterpret_cast<const VT *>(w.dxw);
+    const VT *dxr = reinterpret_cast<const VT *>(w.dxr), *dxw = reinterpret_cast<const VT *>(w.dxw), *dxt = reinterpret_cast<const VT *>(w.dxt);
     VT *ds[2] = {reinterpret_cast<VT *>(w.ds[0]), reinterpret_cast<VT *>(w.ds[1])};
     VF *dD[2] = {reinterpret_cast<VF *>(w.dD[0]), reinterpret_cast<VF *>(w.dD[1])};
     VT *dpol = reinterpret_cast<VT *>(w.dpol);
@@ -196,12 +196,12 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
     const unsigned nbt = (w.nbx + RGB - 1) / RGB;
     // backward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    LAUNCH_RG(RGB, k_tan_back, VT, dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, w.g, (int)P - 1, 1,
+    hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, c.n_hh, (int)P, N, w.dxr, w.dxw, w.dxt);
+    LAUNCH_RG(RGB, k_tan_back, VT, dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, dxt, w.g, (int)P - 1, 1,
                        ds[1], ds[0], dpol);
     int cur = 0;
     for (int t = (int)P - 1; t >= 0; t--) {
-        LAUNCH_RG(RGB, k_tan_back, VT, dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, w.g, t, 0,
+        LAUNCH_RG(RGB, k_tan_back, VT, dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, dxt, w.g, t, 0,
                            ds[cur], ds[cur ^ 1], dpol);
         cur ^= 1;
     }
@@ -229,18 +229,18 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
     const size_t lds = primal_lds(c);
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
-    hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, (int)P, N, w.dxr, w.dxw);
-    hipLaunchKernelGGL(k_egm_X, pgrd, pblk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + 2 * (P - 1),
+    hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, c.n_hh, (int)P, N, w.dxr, w.dxw, w.dxt);
+    hipLaunchKernelGGL(k_egm_X, pgrd, pblk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + c.n_hh * (P - 1),
                        ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, (int)P - 1);
     cur = 0;
     for (int k = 0; k <= (int)P; k++) {
         const int tp = k < (int)P ? (int)P - 1 - k : -1;
         if (k == 0) {
             LAUNCH_RG(RGB, k_fused_back, VT, dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
-                               dxr, dxw, w.g, (int)P - 1, 1, ds[1], ds[0], dpol);
+                               dxr, dxw, dxt, w.g, (int)P - 1, 1, ds[1], ds[0], dpol);
         } else {
             LAUNCH_RG(RGB, k_fused_back, VT, dim3(ctx->nbp + nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, ctx->d_err, tp, ctx->nbp,
-                               dxr, dxw, w.g, (int)P - k, 0, ds[cur], ds[cur ^ 1], dpol);
+                               dxr, dxw, dxt, w.g, (int)P - k, 0, ds[cur], ds[cur ^ 1], dpol);
             cur ^= 1;
         }
     }
@@ -286,9 +286,10 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     geom(VB, w.g); geom(VF, w.gf);
     w.nbx = w.g.nbx; w.nbxf = w.gf.nbx;
     const size_t GV = (size_t)(c.n_a + KV) * c.n_e;   // dD state carries KV virtual rows per column
-    HIPC(ctx, dmalloc(&w.dxhh, 2 * P * N));
+    HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
     HIPC(ctx, dmalloc(&w.dxr, P * N));
     HIPC(ctx, dmalloc(&w.dxw, P * N));
+    HIPC(ctx, dmalloc(&w.dxt, P * N));
     for (int k = 0; k < 2; k++) {
         HIPC(ctx, dmalloc(&w.ds[k], G * N));
         HIPC(ctx, dmalloc(&w.dD[k], GV * N));
@@ -336,7 +337,7 @@ static int fetch_device_error(hank_ctx *ctx) {
 extern "C" {
 
 const char *hank_last_error(const hank_ctx *ctx) { return ctx ? ctx->errmsg : "null context"; }
-int hank_n_hh(const hank_ctx *) { return 2; }
+int hank_n_hh(const hank_ctx *ctx) { return ctx ? ctx->c.n_hh : 0; }
 
 int hank_create(const hank_model *m, hank_ctx **out) {
     if (!m || !out) return HANK_ERR_BAD_ARG;
@@ -348,7 +349,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     *out = ctx;  // returned even on failure so the caller can read hank_last_error, then destroy
     if (m->n_a < 2 || m->n_e < 1 || m->n_e > 16 || m->T < 2)
         return fail(ctx, HANK_ERR_BAD_ARG, "bad shape: n_a=%d (>=2), n_e=%d (1..16), T=%d (>=2)", m->n_a, m->n_e, m->T);
-    if (m->value_fn_id != HANK_VF_KRUSELL_SMITH)
+    if (m->value_fn_id != HANK_VF_KRUSELL_SMITH && m->value_fn_id != HANK_VF_ONE_ASSET_HANK)
         return fail(ctx, HANK_ERR_BAD_ARG, "unknown value function id %d", m->value_fn_id);
     if (!m->a_grid || !m->z_grid || !m->Pi) return fail(ctx, HANK_ERR_BAD_ARG, "null grid pointer");
     for (int i = 1; i < m->n_a; i++)
@@ -361,6 +362,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     Consts &c = ctx->c;
     c.n_a = m->n_a; c.n_e = m->n_e; c.G = m->n_a * m->n_e; c.P = m->T - 1;
     c.beta = m->beta; c.gamma = m->gamma; c.bc = m->borrow_cons;
+    c.n_hh = m->value_fn_id == HANK_VF_ONE_ASSET_HANK ? 3 : 2;
     ctx->T = m->T;
     const size_t P = c.P, G = c.G;
     if ((2 * (size_t)c.n_a + 2) * sizeof(int) > 150 * 1024) return fail(ctx, HANK_ERR_BAD_ARG, "n_a=%d too large for the LDS-staged lottery", c.n_a);
@@ -390,7 +392,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, dmalloc(&ctx->d_ss_value, G));
     ctx->d_ss_D = R.Dseq;
     ctx->nbp = (c.n_a + RBP - 1) / RBP;
-    HIPC(ctx, dmalloc(&ctx->d_xhh, 2 * P));
+    HIPC(ctx, dmalloc(&ctx->d_xhh, (size_t)c.n_hh * P));
     HIPC(ctx, dmalloc(&ctx->d_agg, P));
     HIPC(ctx, dmalloc(&ctx->d_aggpart, P * (size_t)ctx->nbp));
     HIPC(ctx, dmalloc(&ctx->d_err, 4));
@@ -477,7 +479,7 @@ int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
     if (!ctx || !d_xhh) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
     const size_t P = ctx->c.P;
-    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * 2 * P, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyDeviceToDevice, ctx->stream));
     return run_primal(ctx, d_agg_out);
 }
 
@@ -491,8 +493,8 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
     const size_t P = ctx->c.P;
     for (size_t t = 0; t < P; t++)
-        if (!(1.0 + xhh[2 * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
-    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * 2 * P, hipMemcpyHostToDevice, ctx->stream));
+        if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyHostToDevice, ctx->stream));
     int rc = run_primal(ctx, nullptr);
     if (rc) return rc;
     rc = fetch_device_error(ctx);
@@ -525,7 +527,7 @@ int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
     const size_t P = ctx->c.P;
-    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, d_dxhh, sizeof(double) * 2 * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, d_dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyDeviceToDevice, ctx->stream));
     rc = run_jvp(ctx);
     if (rc) return rc;
     if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
@@ -538,7 +540,7 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
     const size_t P = ctx->c.P;
-    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * 2 * P * N, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
     rc = run_jvp(ctx);
     if (rc) return rc;
     HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
@@ -570,8 +572,8 @@ int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh
     if (rc) return rc;
     const size_t P = ctx->c.P;
     HIPC(ctx, join_side(ctx));
-    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * 2 * P, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, d_dxhh, sizeof(double) * 2 * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, d_dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyDeviceToDevice, ctx->stream));
     rc = run_fused(ctx);
     if (rc) return rc;
     if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
@@ -584,12 +586,12 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
     const size_t P = ctx->c.P;
     for (size_t t = 0; t < P; t++)
-        if (!(1.0 + xhh[2 * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
+        if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
     HIPC(ctx, join_side(ctx));
-    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * 2 * P, hipMemcpyHostToDevice, ctx->stream));
-    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * 2 * P * N, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
     rc = run_fused(ctx);
     if (rc) return rc;
     rc = fetch_device_error(ctx);
@@ -676,16 +678,16 @@ static int granular_backward(hank_ctx *ctx, const double *value_next, const doub
     Scratch sc;
     double *Vin, *xt, *sK, *kc, *A, *B, *u, *v, *pol, *Vout;
     int *ib;
-    HIPC(ctx, sc.alloc(&Vin, G)); HIPC(ctx, sc.alloc(&xt, 2)); HIPC(ctx, sc.alloc(&sK, G)); HIPC(ctx, sc.alloc(&kc, G));
+    HIPC(ctx, sc.alloc(&Vin, G)); HIPC(ctx, sc.alloc(&xt, 3)); HIPC(ctx, sc.alloc(&sK, G)); HIPC(ctx, sc.alloc(&kc, G));
     HIPC(ctx, sc.alloc(&A, G)); HIPC(ctx, sc.alloc(&B, G)); HIPC(ctx, sc.alloc(&u, G)); HIPC(ctx, sc.alloc(&v, G));
     HIPC(ctx, sc.alloc(&pol, G)); HIPC(ctx, sc.alloc(&Vout, G)); HIPC(ctx, sc.alloc(&ib, G));
     if (!(1.0 + xhh_t[0] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive");
     HIPC(ctx, hipMemcpyAsync(Vin, value_next, sizeof(double) * G, hipMemcpyHostToDevice, s));
-    HIPC(ctx, hipMemcpyAsync(xt, xhh_t, sizeof(double) * 2, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemcpyAsync(xt, xhh_t, sizeof(double) * c.n_hh, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
     hipLaunchKernelGGL(k_egm_X, grd, blk, primal_lds(c), s, c, Vin, xt, sK, kc, ctx->d_err, 0);
-    hipLaunchKernelGGL(k_egm_Y, grd, blk, 0, s, c, sK, xhh_t[0], xhh_t[1], pol, ib, A, B, u, v, Vout, ctx->d_err, 0);
+    hipLaunchKernelGGL(k_egm_Y, grd, blk, 0, s, c, sK, xhh_t[0], xhh_t[1], c.n_hh > 2 ? xhh_t[2] : 0.0, pol, ib, A, B, u, v, Vout, ctx->d_err, 0);
     HIPC(ctx, hipGetLastError());
     const bool was_done = ctx->primal_done;
     int rc = fetch_device_error(ctx);
@@ -694,17 +696,21 @@ static int granular_backward(hank_ctx *ctx, const double *value_next, const doub
     HIPC(ctx, hipMemcpyAsync(value_out, Vout, sizeof(double) * G, hipMemcpyDeviceToHost, s));
     HIPC(ctx, hipMemcpyAsync(policy_out, pol, sizeof(double) * G, hipMemcpyDeviceToHost, s));
     if (N > 0) {
-        double *dVin, *dr, *dw, *ds, *dpol, *dV;
+        double *dVin, *dr, *dw, *dtr = nullptr, *ds, *dpol, *dV;
         HIPC(ctx, sc.alloc(&dVin, G * N)); HIPC(ctx, sc.alloc(&dr, N)); HIPC(ctx, sc.alloc(&dw, N));
         HIPC(ctx, sc.alloc(&ds, G * N)); HIPC(ctx, sc.alloc(&dpol, G * N)); HIPC(ctx, sc.alloc(&dV, G * N));
-        std::vector<double> hr(N), hw(N);
-        for (int n = 0; n < N; n++) { hr[n] = dxhh_t[2 * n]; hw[n] = dxhh_t[2 * n + 1]; }
+        std::vector<double> hr(N), hw(N), ht(N);
+        for (int n = 0; n < N; n++) { hr[n] = dxhh_t[c.n_hh * n]; hw[n] = dxhh_t[c.n_hh * n + 1]; ht[n] = c.n_hh > 2 ? dxhh_t[c.n_hh * n + 2] : 0.0; }
+        if (c.n_hh > 2) {
+            HIPC(ctx, sc.alloc(&dtr, N));
+            HIPC(ctx, hipMemcpyAsync(dtr, ht.data(), sizeof(double) * N, hipMemcpyHostToDevice, s));
+        }
         HIPC(ctx, hipMemcpyAsync(dVin, dvalue_next, sizeof(double) * G * N, hipMemcpyHostToDevice, s));
         HIPC(ctx, hipMemcpyAsync(dr, hr.data(), sizeof(double) * N, hipMemcpyHostToDevice, s));
         HIPC(ctx, hipMemcpyAsync(dw, hw.data(), sizeof(double) * N, hipMemcpyHostToDevice, s));
         const unsigned nb = (unsigned)((G * N + 255) / 256);
-        hipLaunchKernelGGL(k_tan_X, dim3(nb), dim3(256), 0, s, c, kc, sK, xhh_t[0], dr, dw, N, dVin, ds);
-        hipLaunchKernelGGL(k_tan_Y, dim3(nb), dim3(256), 0, s, c, ib, A, B, u, v, dr, dw, N, ds, dpol, dV);
+        hipLaunchKernelGGL(k_tan_X, dim3(nb), dim3(256), 0, s, c, kc, sK, xhh_t[0], dr, dw, dtr, N, dVin, ds);
+        hipLaunchKernelGGL(k_tan_Y, dim3(nb), dim3(256), 0, s, c, ib, A, B, u, v, dr, dw, dtr, N, ds, dpol, dV);
         HIPC(ctx, hipGetLastError());
         HIPC(ctx, hipMemcpyAsync(dvalue_out, dV, sizeof(double) * G * N, hipMemcpyDeviceToHost, s));
         HIPC(ctx, hipMemcpyAsync(dpolicy_out, dpol, sizeof(double) * G * N, hipMemcpyDeviceToHost, s));

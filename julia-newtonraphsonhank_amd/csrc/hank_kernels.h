@@ -23,6 +23,7 @@ constexpr int RBP = 32;        // rows (wealth points) per block in the primal k
 
 struct Consts {
     int n_a, n_e, G, P;
+    int n_hh;   // household inputs per period: 2 = (r, w) Krusell-Smith; 3 = (r, w, tr) one-asset HANK (lump-sum transfer)
     double beta, gamma, bc;
     const double *a, *z, *Pi;  // device
 };
@@ -130,11 +131,14 @@ __device__ __forceinline__ T mix_sum(T acc, const T *V, int vs, const double *P,
     return acc;
 }
 
+// household inputs of period t: xhh[n_hh*t + k]; the lump-sum transfer is 0 for families without one
+__device__ __forceinline__ double hh_tr(const Consts &c, const double *xhh, int t) { return c.n_hh > 2 ? xhh[c.n_hh * t + 2] : 0.0; }
+
 // ---- EGM step, split in the two halves that fuse across the period boundary ------------------
 // X half (KrusellSmith.jl:59-62): from V_{t+1} (all e2 of this row, in LDS) to the endogenous
 // knot s_t[a,e] and kc = d s / d E  (= rho * d c / d E).
 __device__ inline void egm_X(const Consts &c, const double *Vsh, const double *Pish, int row, int a,
-                             int e, double r, double w, double *s_out, double *kc_out, int *err,
+                             int e, double r, double w, double tr, double *s_out, double *kc_out, int *err,
                              int t) {
     const double E = mix_sum(Vsh[row] * Pish[e], Vsh + row, RBP, Pish + e, c.n_e, 1, c.n_e);
     const double bE = E * c.beta;
@@ -142,7 +146,7 @@ __device__ inline void egm_X(const Consts &c, const double *Vsh, const double *P
     if (pow_domain_error(bE, ex)) set_err(err, ERR_DOMAIN, t, e, a);
     const double cm = pow_crra(bE, ex);
     const double rho = 1.0 / (1.0 + r);
-    st_mode<HANK_ST_REC>(s_out, rho * ((cm - w * c.z[e]) + c.a[a]));
+    st_mode<HANK_ST_REC>(s_out, rho * ((cm - (w * c.z[e] + tr)) + c.a[a]));
     // d cmat/dE = beta*ex*(bE)^(ex-1)  (Dual^Real, ForwardDiff dual.jl:563-572)
     st_mode<HANK_ST_REC>(kc_out, rho * (c.beta * ex * (cm / bE)));
 }
@@ -156,7 +160,7 @@ struct YOut {
 };
 // `guess` (>= 0): the bracket of the same point one period later — brackets move by a few knots per
 // period, so a probe there plus a short gallop replaces the 11 dependent loads of a cold bisection.
-__device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, double r, double w,
+__device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, double r, double w, double tr,
                              int *err, int t, int guess) {
     YOut o;
     const int n = c.n_a;
@@ -220,7 +224,7 @@ __device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, do
     }
     g = (g > bc) ? g : ((bc > g) ? bc : (signbit(g) ? bc : g));
     const double opr = 1.0 + r;
-    const double cg = (opr * x + w * c.z[e]) - g;
+    const double cg = (opr * x + (w * c.z[e] + tr)) - g;
     if (pow_domain_error(cg, -c.gamma)) set_err(err, ERR_DOMAIN, t, e, a);
     const double u = pow_crra(cg, -c.gamma);
     o.g = g;
@@ -244,16 +248,16 @@ __global__ void k_egm_X(Consts c, const double *Vin, const double *xt, double *s
     for (int k = threadIdx.x; k < c.n_e * c.n_e; k += blockDim.x) Pish[k] = c.Pi[k];
     if (a < c.n_a) Vsh[e * RBP + row] = Vin[e * c.n_a + a];
     __syncthreads();
-    if (a < c.n_a) egm_X(c, Vsh, Pish, row, a, e, xt[0], xt[1], &s_out[e * c.n_a + a], &kc_out[e * c.n_a + a], err, t);
+    if (a < c.n_a) egm_X(c, Vsh, Pish, row, a, e, xt[0], xt[1], c.n_hh > 2 ? xt[2] : 0.0, &s_out[e * c.n_a + a], &kc_out[e * c.n_a + a], err, t);
 }
 
 // Y only (granular step): record slot pointers are for ONE period
-__global__ void k_egm_Y(Consts c, const double *s, double r, double w, double *pol, int *ib,
+__global__ void k_egm_Y(Consts c, const double *s, double r, double w, double tr, double *pol, int *ib,
                         double *A, double *B, double *u, double *v, double *Vout, int *err, int t) {
     const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
     const int a = blockIdx.x * RBP + row;
     if (a >= c.n_a) return;
-    const YOut o = egm_Y(c, s + e * c.n_a, a, e, r, w, err, t, -1);
+    const YOut o = egm_Y(c, s + e * c.n_a, a, e, r, w, tr, err, t, -1);
     const int off = e * c.n_a + a;
     pol[off] = o.g; ib[off] = o.ib; A[off] = o.A; B[off] = o.B; u[off] = o.u; v[off] = o.v;
     Vout[off] = o.V;
@@ -270,9 +274,9 @@ __device__ inline void egm_step_body(const Consts &c, const Record &R, const dou
     for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
     const size_t base = (size_t)t * c.G;
     if (a < c.n_a) {
-        const double r = xhh[2 * t], w = xhh[2 * t + 1];
+        const double r = xhh[c.n_hh * t], w = xhh[c.n_hh * t + 1], tr = hh_tr(c, xhh, t);
         const int guess = (t + 1 < c.P) ? R.ib[base + c.G + (size_t)e * c.n_a + a] : -1;
-        const YOut o = egm_Y(c, R.s + base + (size_t)e * c.n_a, a, e, r, w, err, t, guess);
+        const YOut o = egm_Y(c, R.s + base + (size_t)e * c.n_a, a, e, r, w, tr, err, t, guess);
         const size_t off = base + (size_t)e * c.n_a + a;
         st_mode<HANK_ST_REC>(&R.pol[off], o.g); st_mode_i<HANK_ST_REC>(&R.ib[off], o.ib); st_mode<HANK_ST_REC>(&R.A[off], o.A);
         st_mode<HANK_ST_REC>(&R.B[off], o.B); st_mode<HANK_ST_REC>(&R.u[off], o.u); st_mode<HANK_ST_REC>(&R.v[off], o.v);
@@ -280,9 +284,9 @@ __device__ inline void egm_step_body(const Consts &c, const Record &R, const dou
     }
     __syncthreads();
     if (t > 0 && a < c.n_a) {
-        const double r1 = xhh[2 * (t - 1)], w1 = xhh[2 * (t - 1) + 1];
+        const double r1 = xhh[c.n_hh * (t - 1)], w1 = xhh[c.n_hh * (t - 1) + 1], tr1 = hh_tr(c, xhh, t - 1);
         const size_t off1 = base - c.G + (size_t)e * c.n_a + a;
-        egm_X(c, Vsh, Pish, row, a, e, r1, w1, &R.s[off1], &R.kc[off1], err, t - 1);
+        egm_X(c, Vsh, Pish, row, a, e, r1, w1, tr1, &R.s[off1], &R.kc[off1], err, t - 1);
     }
 }
 __global__ void k_egm_step(Consts c, Record R, const double *xhh, int t, int *err) {
@@ -440,13 +444,16 @@ __global__ void k_reduce_parts(const double *__restrict__ parts, int nb, int N, 
 constexpr int KV = 16;
 struct TanGeom { int N, NC, lgNC, nbx, ss; };   // ss: source-stationary forward kernel (see tan_fwd_body)   // nbx = regular row blocks = ceil(n_a / (64/NC))
 
-// (n_hh, P, N) column-major  ->  dxr[P][N], dxw[P][N]
-__global__ void k_tan_in(const double *__restrict__ dxhh, int P, int N, double *__restrict__ dxr, double *__restrict__ dxw) {
+// (n_hh, P, N) column-major  ->  dxr[P][N], dxw[P][N] (, dxt[P][N] when the family has a transfer input)
+__global__ void k_tan_in(const double *__restrict__ dxhh, int n_hh, int P, int N, double *__restrict__ dxr, double *__restrict__ dxw,
+                         double *__restrict__ dxt) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P * N) return;
     const int t = idx / N, n = idx - t * N;
-    dxr[idx] = dxhh[0 + 2 * ((size_t)t + (size_t)P * n)];
-    dxw[idx] = dxhh[1 + 2 * ((size_t)t + (size_t)P * n)];
+    const double *x = dxhh + (size_t)n_hh * ((size_t)t + (size_t)P * n);
+    dxr[idx] = x[0];
+    dxw[idx] = x[1];
+    if (n_hh > 2) dxt[idx] = x[2];
 }
 // dagg[P][N] -> (P, N) column-major
 __global__ void k_tan_out(const double *__restrict__ dagg, int P, int N, double *__restrict__ out) {
@@ -494,7 +501,7 @@ __device__ __forceinline__ double vsub(double a, double b) { return a - b; }
 
 template <int RG, typename VT>
 __device__ inline void tan_back_body(const Consts &c, const Record &R, const double *__restrict__ xhh, const VT *__restrict__ dxr,
-           const VT *__restrict__ dxw, const TanGeom &g, int t, int first, const VT *__restrict__ dsIn,
+           const VT *__restrict__ dxw, const VT *__restrict__ dxt, const TanGeom &g, int t, int first, const VT *__restrict__ dsIn,
            VT *__restrict__ dsOut, VT *__restrict__ dpol, int bidx, int bidy, VT (*dVsh)[16 * 64], double *Pish) {
     const int nthr = 64 * c.n_e;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
@@ -547,13 +554,14 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
         }
     }
     const bool nok = n < g.N;
-    VT dr, dw, dr1, dw1;
-    vzero(dr); vzero(dw); vzero(dr1); vzero(dw1);
+    VT dr, dw, dr1, dw1, dtr, dtr1;     // dtr: tangent of the lump-sum transfer (families with n_hh = 3)
+    vzero(dr); vzero(dw); vzero(dr1); vzero(dw1); vzero(dtr); vzero(dtr1);
     if (nok) {
         dr = dxr[(size_t)t * N + n]; dw = dxw[(size_t)t * N + n];
         dr1 = dxr[(size_t)txc * N + n]; dw1 = dxw[(size_t)txc * N + n];
+        if (c.n_hh > 2) { dtr = dxt[(size_t)t * N + n]; dtr1 = dxt[(size_t)txc * N + n]; }
     }
-    const double ze = c.z[e], rho1 = 1.0 / (1.0 + xhh[2 * txc]);
+    const double ze = c.z[e], rho1 = 1.0 / (1.0 + xhh[c.n_hh * txc]);
     VT d0[RG], d1[RG];
 #pragma unroll
     for (int q = 0; q < RG; q++) {
@@ -571,7 +579,7 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
         if (valid[q] && !first) {
             const VT dg = vadd(vmul(cA[q], d0[q]), vmul(cB[q], d1[q]));
             st_mode<HANK_ST_DPOL>(&dpol[((size_t)t * c.G + (size_t)e * c.n_a + a[q]) * N + n], dg);
-            dV = vadd(vmul(cu[q], dr), vmul(cv[q], vsub(vadd(vmul(xa[q], dr), vmul(ze, dw)), dg)));
+            dV = vadd(vmul(cu[q], dr), vmul(cv[q], vsub(vadd(vmul(xa[q], dr), vadd(vmul(ze, dw), dtr)), dg)));
         }
         dVsh[q][e * 64 + lane] = dV;
     }
@@ -582,7 +590,7 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
         if (valid[q]) {
             const VT dE = mix_sum(vmul(Pish[e], dVsh[q][lane]), &dVsh[q][lane], 64, Pish + e, c.n_e, 1, c.n_e);
             st_mode<HANK_ST_STATE>(&dsOut[((size_t)e * c.n_a + a[q]) * N + n],
-                                   vsub(vmul(ck[q], dE), vmul(rho1, vadd(vmul(ze, dw1), vmul(cs[q], dr1)))));
+                                   vsub(vmul(ck[q], dE), vmul(rho1, vadd(vadd(vmul(ze, dw1), dtr1), vmul(cs[q], dr1)))));
         }
     }
 }
@@ -590,11 +598,11 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
 template <int RG, typename VT>
 __global__ void __launch_bounds__(1024)
 k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const VT *__restrict__ dxr,
-           const VT *__restrict__ dxw, TanGeom g, int t, int first, const VT *__restrict__ dsIn,
+           const VT *__restrict__ dxw, const VT *__restrict__ dxt, TanGeom g, int t, int first, const VT *__restrict__ dsIn,
            VT *__restrict__ dsOut, VT *__restrict__ dpol) {
     __shared__ VT dVsh[RG][16 * 64];
     __shared__ double Pish[256];
-    tan_back_body<RG, VT>(c, R, xhh, dxr, dxw, g, t, first, dsIn, dsOut, dpol, blockIdx.x, blockIdx.y, dVsh, Pish);
+    tan_back_body<RG, VT>(c, R, xhh, dxr, dxw, dxt, g, t, first, dsIn, dsOut, dpol, blockIdx.x, blockIdx.y, dVsh, Pish);
 }
 
 // the dual-sweep backward launch: blocks [0, nbp) of grid row 0 run the PRIMAL EGM step of period tp,
@@ -603,7 +611,7 @@ k_tan_back(Consts c, Record R, const double *__restrict__ xhh, const VT *__restr
 template <int RG, typename VT>
 __global__ void __launch_bounds__(1024)
 k_fused_back(Consts c, Record R, const double *__restrict__ xhh, int *err, int tp, int nbp,
-             const VT *__restrict__ dxr, const VT *__restrict__ dxw, TanGeom g, int tt, int first,
+             const VT *__restrict__ dxr, const VT *__restrict__ dxw, const VT *__restrict__ dxt, TanGeom g, int tt, int first,
              const VT *__restrict__ dsIn, VT *__restrict__ dsOut, VT *__restrict__ dpol) {
     __shared__ VT dVsh[RG][16 * 64];
     __shared__ double Pish[256];
@@ -613,7 +621,7 @@ k_fused_back(Consts c, Record R, const double *__restrict__ xhh, int *err, int t
         return;
     }
     if (tt < 0) return;
-    tan_back_body<RG, VT>(c, R, xhh, dxr, dxw, g, tt, first, dsIn, dsOut, dpol, blockIdx.x - nbp, blockIdx.y, dVsh, Pish);
+    tan_back_body<RG, VT>(c, R, xhh, dxr, dxw, dxt, g, tt, first, dsIn, dsOut, dpol, blockIdx.x - nbp, blockIdx.y, dVsh, Pish);
 }
 
 // one forward period: segment gather of the lottery tangent (ForwardIteration.jl:37-99 under
@@ -871,18 +879,18 @@ k_fused_fwd(Consts c, Record R, int tp, int nbp, double *__restrict__ paggpart, 
 // ---- granular tangent halves (hank_backward_step_dual) ---------------------------------------
 // X-tangent alone: dV' (G,N col-major) -> ds[e][a][N]
 __global__ void k_tan_X(Consts c, const double *kc, const double *s, double r, const double *dr,
-                        const double *dw, int N, const double *dVin_colmajor, double *dsOut) {
+                        const double *dw, const double *dtr, int N, const double *dVin_colmajor, double *dsOut) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= c.G * N) return;
     const int n = idx % N, pt = idx / N, e = pt / c.n_a, a = pt - e * c.n_a;
     double dE = 0.0;
     for (int e2 = 0; e2 < c.n_e; e2++) dE += dVin_colmajor[(size_t)n * c.G + (size_t)e2 * c.n_a + a] * c.Pi[e + c.n_e * e2];
     const double rho = 1.0 / (1.0 + r);
-    dsOut[(size_t)pt * N + n] = kc[pt] * dE - rho * (c.z[e] * dw[n] + s[pt] * dr[n]);
+    dsOut[(size_t)pt * N + n] = kc[pt] * dE - rho * ((c.z[e] * dw[n] + (dtr ? dtr[n] : 0.0)) + s[pt] * dr[n]);
 }
 // Y-tangent alone: ds -> dpol, dV (both (G,N) col-major for the caller)
 __global__ void k_tan_Y(Consts c, const int *ib, const double *A, const double *B, const double *u,
-                        const double *v, const double *dr, const double *dw, int N,
+                        const double *v, const double *dr, const double *dw, const double *dtr, int N,
                         const double *ds, double *dpol_cm, double *dV_cm) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= c.G * N) return;
@@ -891,7 +899,7 @@ __global__ void k_tan_Y(Consts c, const int *ib, const double *A, const double *
     const double *col = ds + ((size_t)e * c.n_a) * N + n;
     const double dg = A[pt] * col[(size_t)i * N] + B[pt] * col[(size_t)(i + 1) * N];
     dpol_cm[(size_t)n * c.G + pt] = dg;
-    dV_cm[(size_t)n * c.G + pt] = u[pt] * dr[n] + v[pt] * ((c.a[a] * dr[n] + c.z[e] * dw[n]) - dg);
+    dV_cm[(size_t)n * c.G + pt] = u[pt] * dr[n] + v[pt] * ((c.a[a] * dr[n] + (c.z[e] * dw[n] + (dtr ? dtr[n] : 0.0))) - dg);
 }
 
 // ---- granular forward step for ARBITRARY policies (atomic scatter; parity tests of a6/a7) -----
