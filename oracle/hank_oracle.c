@@ -223,14 +223,15 @@ static inline dual interp_flat(const dual *knots, const double *vals, int n, dou
 
 /* ---- ValueFunction: one EGM step (KrusellSmith.jl:43-83) ---------------------------------
  * value_next, Value, KD: n_a x n_e dual matrices (column-major); r, w duals.               */
-int FN(orc_value_function)(const orc_model *m, const double *value_next_, const double *r_,
-                           const double *w_, double *Value_, double *KD_) {
+static int FN(value_function_impl)(const orc_model *m, const double *value_next_, const double *r_,
+                                   const double *w_, const double *tr_, double *Value_, double *KD_) {
     const int n_a = m->n_a, n_e = m->n_e;
     const dual *value_next = (const dual *)value_next_;
     dual *Value = (dual *)Value_, *KD = (dual *)KD_;
-    dual r, w;
+    dual r, w, tr = d_const(0.0);
     memcpy(&r, r_, sizeof(dual));
     memcpy(&w, w_, sizeof(dual));
+    if (tr_) memcpy(&tr, tr_, sizeof(dual));
     int status = ORC_OK;
     dual *knots = (dual *)malloc(sizeof(dual) * (size_t)n_a);
 
@@ -245,7 +246,9 @@ int FN(orc_value_function)(const orc_model *m, const double *value_next_, const 
                 acc = d_add(acc, d_mul_r(value_next[ia + n_a * e2], m->Pi[e + n_e * e2]));
             dual cm = d_pow_r(d_mul_r(acc, m->beta), -1.0 / m->gamma, &status);
             /* :62 impliedstate = (1/(1+r)) .* (cmat .- (w .* labor) .+ policy_a) */
-            dual t = d_add_r(d_sub(cm, d_mul_r(w, m->z[e])), m->a[ia]);
+            dual inc = d_mul_r(w, m->z[e]);           /* labour income; + the lump-sum transfer in the HANK family */
+            if (tr_) inc = d_add(inc, tr);
+            dual t = d_add_r(d_sub(cm, inc), m->a[ia]);
             knots[ia] = d_mul(rho, t);
         }
         /* Interpolations check: knots sorted and unique (values) */
@@ -257,7 +260,9 @@ int FN(orc_value_function)(const orc_model *m, const double *value_next_, const 
             /* :76 borrowing constraint */
             g = d_max_r(g, m->borrow_cons);
             /* :79 c_grid = (1+r).*a .+ (w.*z) .- g */
-            dual c = d_sub(d_add(d_mul_r(one_plus_r, m->a[ia]), d_mul_r(w, m->z[e])), g);
+            dual inc = d_mul_r(w, m->z[e]);
+            if (tr_) inc = d_add(inc, tr);
+            dual c = d_sub(d_add(d_mul_r(one_plus_r, m->a[ia]), inc), g);
             /* :80 value_current = (1+r) .* (c_grid .^ (-γ)) */
             Value[ia + n_a * e] = d_mul(one_plus_r, d_pow_r(c, -m->gamma, &status));
             KD[ia + n_a * e] = g;
@@ -267,14 +272,25 @@ int FN(orc_value_function)(const orc_model *m, const double *value_next_, const 
     return status;
 }
 
+int FN(orc_value_function)(const orc_model *m, const double *value_next_, const double *r_,
+                           const double *w_, double *Value_, double *KD_) {
+    return FN(value_function_impl)(m, value_next_, r_, w_, NULL, Value_, KD_);
+}
+/* The one-asset HANK family (NOT in the reference): the same EGM step with a lump-sum
+ * transfer tr in the budget, cash on hand (1+r) a + w z_e + tr. Parity unpinned by construction.          */
+int FN(orc_value_function_tr)(const orc_model *m, const double *value_next_, const double *r_,
+                              const double *w_, const double *tr_, double *Value_, double *KD_) {
+    return FN(value_function_impl)(m, value_next_, r_, w_, tr_, Value_, KD_);
+}
+
 /* ---- BackwardIteration (BackwardIteration.jl:46-116) -------------------------------------
  * xr, xw: dual paths of r_t, w_t, t = 1..P (the only xVals entries KS's value_fn reads,
  * KrusellSmith.jl:53-54). Terminal value = ss_end.value with zero partials (:85).
  * policy_seq: P dual matrices, period-major (seqs_data[j][t], :110-112).                    */
-int FN(orc_backward_iteration)(const orc_model *m, int P, const double *xr_, const double *xw_,
-                               const double *ss_end_value, double *policy_seq_) {
+static int FN(backward_iteration_impl)(const orc_model *m, int P, const double *xr_, const double *xw_, const double *xt_,
+                                       const double *ss_end_value, double *policy_seq_) {
     const int G = m->n_a * m->n_e;
-    const dual *xr = (const dual *)xr_, *xw = (const dual *)xw_;
+    const dual *xr = (const dual *)xr_, *xw = (const dual *)xw_, *xt = (const dual *)xt_;
     dual *policy_seq = (dual *)policy_seq_;
     dual *value = (dual *)malloc(sizeof(dual) * (size_t)G);
     dual *vnew = (dual *)malloc(sizeof(dual) * (size_t)G);
@@ -282,9 +298,9 @@ int FN(orc_backward_iteration)(const orc_model *m, int P, const double *xr_, con
     int status = ORC_OK;
     for (int i = 1; i <= P; i++) {
         int t = P + 1 - i - 1; /* Julia t = T - i (1-based) -> 0-based */
-        int st = FN(orc_value_function)(m, (const double *)value, (const double *)&xr[t],
-                                        (const double *)&xw[t], (double *)vnew,
-                                        (double *)(policy_seq + (size_t)t * G));
+        int st = FN(value_function_impl)(m, (const double *)value, (const double *)&xr[t],
+                                         (const double *)&xw[t], xt ? (const double *)&xt[t] : NULL, (double *)vnew,
+                                         (double *)(policy_seq + (size_t)t * G));
         if (st != ORC_OK && status == ORC_OK) status = st;
         dual *tmp = value;
         value = vnew;
@@ -293,6 +309,16 @@ int FN(orc_backward_iteration)(const orc_model *m, int P, const double *xr_, con
     free(value);
     free(vnew);
     return status;
+}
+
+int FN(orc_backward_iteration)(const orc_model *m, int P, const double *xr_, const double *xw_,
+                               const double *ss_end_value, double *policy_seq_) {
+    return FN(backward_iteration_impl)(m, P, xr_, xw_, NULL, ss_end_value, policy_seq_);
+}
+
+int FN(orc_backward_iteration_tr)(const orc_model *m, int P, const double *xr_, const double *xw_, const double *xt_,
+                                  const double *ss_end_value, double *policy_seq_) {
+    return FN(backward_iteration_impl)(m, P, xr_, xw_, xt_, ss_end_value, policy_seq_);
 }
 
 /* ---- transition_step (ForwardIteration.jl:37-99) -----------------------------------------
@@ -378,6 +404,18 @@ int FN(orc_household_block)(const orc_model *m, int P, const double *xr, const d
     const size_t G = (size_t)m->n_a * m->n_e;
     double *pol = policy_seq_out ? policy_seq_out : (double *)malloc(sizeof(dual) * G * (size_t)P);
     int st = FN(orc_backward_iteration)(m, P, xr, xw, ss_end_value, pol);
+    FN(orc_forward_iteration)(m, P, pol, ss_init_D, agg, NULL);
+    if (!policy_seq_out) free(pol);
+    return st;
+}
+
+/* household block of the one-asset HANK family: dual paths r_t, w_t, tr_t */
+int FN(orc_household_block_tr)(const orc_model *m, int P, const double *xr, const double *xw, const double *xt,
+                               const double *ss_end_value, const double *ss_init_D, double *agg,
+                               double *policy_seq_out) {
+    const size_t G = (size_t)m->n_a * m->n_e;
+    double *pol = policy_seq_out ? policy_seq_out : (double *)malloc(sizeof(dual) * G * (size_t)P);
+    int st = FN(backward_iteration_impl)(m, P, xr, xw, xt, ss_end_value, pol);
     FN(orc_forward_iteration)(m, P, pol, ss_init_D, agg, NULL);
     if (!policy_seq_out) free(pol);
     return st;

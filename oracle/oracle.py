@@ -102,27 +102,41 @@ class Oracle:
         out[: x.size] = x
         return out
 
-    def value_function(self, value_next, r, w, N: int):
-        """ValueFunction (KrusellSmith.jl:43-83). Returns (status, Value, KD) as (n_a,n_e,1+N)."""
+    def value_function(self, value_next, r, w, N: int, tr=None):
+        """ValueFunction (KrusellSmith.jl:43-83). Returns (status, Value, KD) as (n_a,n_e,1+N).
+        `tr` (a dual, like r and w): the lump-sum transfer of the one-asset HANK family (not in the reference)."""
         vin = self._mat_to_mem(value_next, N)
         V = np.empty_like(vin)
         KD = np.empty_like(vin)
-        f = _fn("orc_value_function", N)
-        f.restype = C.c_int
-        st = f(C.byref(self.m), _dp(vin), _dp(self._scalar(r, N)), _dp(self._scalar(w, N)), _dp(V), _dp(KD))
+        if tr is None:
+            f = _fn("orc_value_function", N)
+            f.restype = C.c_int
+            st = f(C.byref(self.m), _dp(vin), _dp(self._scalar(r, N)), _dp(self._scalar(w, N)), _dp(V), _dp(KD))
+        else:
+            f = _fn("orc_value_function_tr", N)
+            f.restype = C.c_int
+            st = f(C.byref(self.m), _dp(vin), _dp(self._scalar(r, N)), _dp(self._scalar(w, N)), _dp(self._scalar(tr, N)), _dp(V), _dp(KD))
         return st, self._mem_to_mat(V, N), self._mem_to_mat(KD, N)
 
-    def backward_iteration(self, xr, xw, ss_end_value, N: int):
-        """BackwardIteration (BackwardIteration.jl:46-116). xr/xw: (P,1+N). -> (status, (P,n_a,n_e,1+N))."""
+    def backward_iteration(self, xr, xw, ss_end_value, N: int, xt=None):
+        """BackwardIteration (BackwardIteration.jl:46-116). xr/xw: (P,1+N). -> (status, (P,n_a,n_e,1+N)).
+        `xt` (P,1+N): the transfer path of the one-asset HANK family."""
         xr = np.ascontiguousarray(xr, dtype=np.float64)
         xw = np.ascontiguousarray(xw, dtype=np.float64)
         P = xr.shape[0]
         assert xr.shape == (P, 1 + N) and xw.shape == (P, 1 + N)
         vT = np.ascontiguousarray(np.asarray(ss_end_value, dtype=np.float64).T)  # [e][a]
         pol = np.empty((P, self.n_e, self.n_a, 1 + N))
-        f = _fn("orc_backward_iteration", N)
-        f.restype = C.c_int
-        st = f(C.byref(self.m), P, _dp(xr), _dp(xw), _dp(vT), _dp(pol))
+        if xt is None:
+            f = _fn("orc_backward_iteration", N)
+            f.restype = C.c_int
+            st = f(C.byref(self.m), P, _dp(xr), _dp(xw), _dp(vT), _dp(pol))
+        else:
+            xt = np.ascontiguousarray(xt, dtype=np.float64)
+            assert xt.shape == (P, 1 + N)
+            f = _fn("orc_backward_iteration_tr", N)
+            f.restype = C.c_int
+            st = f(C.byref(self.m), P, _dp(xr), _dp(xw), _dp(xt), _dp(vT), _dp(pol))
         return st, pol.transpose(0, 2, 1, 3).copy()
 
     def transition_step(self, policy, D_prev, N: int):
@@ -147,9 +161,9 @@ class Oracle:
             return agg, Dseq.transpose(0, 2, 1, 3).copy()
         return agg
 
-    def household_block(self, xr, xw, ss_end_value, ss_init_D, N: int):
+    def household_block(self, xr, xw, ss_end_value, ss_init_D, N: int, xt=None):
         """ForwardIteration(BackwardIteration(...)) -> (status, agg (P,1+N), policy_seq)."""
-        st, pol = self.backward_iteration(xr, xw, ss_end_value, N)
+        st, pol = self.backward_iteration(xr, xw, ss_end_value, N, xt)
         agg = self.forward_iteration(pol, ss_init_D, N)
         return st, agg, pol
 

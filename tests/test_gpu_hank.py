@@ -1,0 +1,102 @@
+"""The second native value-function family (one-asset HANK: EGM step with a lump-sum transfer, three household
+inputs r, om, Tr). NOT in the reference: parity is unpinned by construction — the GPU path is
+checked against the oracle's restatement of the same family, against central differences, and by solving the
+perfect-foresight response to a monetary shock. Tolerance as for the KS family: rel 1e-10 + abs 1e-12."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def close(a, b, rel=1e-10, abs_=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    scale = max(np.max(np.abs(b)), 1e-300)
+    err = np.max(np.abs(a - b))
+    assert err <= abs_ + rel * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.fixture(scope="module")
+def hank_model():
+    from examples.solve_hank import build
+    return build(80, 3, 40)
+
+
+def _paths(m, ss, P, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.arange(P)
+    x = np.stack([ss.vars["r"] + 0.002 * 0.8 ** t, ss.vars["om"] * (1 + 0.01 * 0.7 ** t), ss.vars["Tr"] * (1 - 0.02 * 0.9 ** t)])
+    return x, rng
+
+
+@pytest.mark.parametrize("N", [1, 4, 32])
+def test_household_block_matches_oracle(hank, hank_model, N):
+    from oracle.oracle import Oracle, pad_N
+    m, ss = hank_model
+    P = m.compspec.T - 1
+    x, rng = _paths(m, ss, P)
+    y = rng.standard_normal((3, P, N))
+    hb = hank.household_block(m)
+    assert hb.n_hh == 3
+    hb.set_boundary(ss.value, ss.D)
+    agg, dagg = hb.primal_jvp(x, y)
+    wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    orc = Oracle(wd.grid, pdm.grid, pdm.transition, m.params.β, m.params.γ, m.params.borrow_cons)
+    Nc = pad_N(N)
+    xd = np.zeros((3, P, 1 + Nc))
+    xd[..., 0] = x
+    xd[..., 1:1 + N] = y
+    st, oagg, opol = orc.household_block(xd[0], xd[1], ss.value, ss.D, Nc, xt=xd[2])
+    assert st == 0
+    close(agg, oagg[:, 0])
+    close(dagg, oagg[:, 1:1 + N])
+    close(hb.policy_seq().transpose(2, 0, 1), opol[..., 0])
+    close(hb.dpolicy_seq(N).transpose(2, 0, 1, 3), opol[..., 1:1 + N])
+    # the split schedule (hank_primal, then hank_jvp) gives the same numbers bit for bit
+    np.testing.assert_array_equal(hb.primal(x), agg)
+    np.testing.assert_array_equal(hb.jvp(y), dagg)
+
+
+def test_transfer_tangent_against_central_differences(hank, hank_model):
+    m, ss = hank_model
+    P = m.compspec.T - 1
+    x, rng = _paths(m, ss, P, 1)
+    y = np.zeros((3, P, 1))
+    y[2, :, 0] = rng.standard_normal(P)          # a pure transfer direction
+    hb = hank.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    _, dagg = hb.primal_jvp(x, y)
+    h_ = 1e-6
+    fd = (hb.primal(x + h_ * y[..., 0]) - hb.primal(x - h_ * y[..., 0])) / (2 * h_)
+    close(dagg[:, 0], fd, rel=2e-6, abs_=1e-8)
+
+
+def test_granular_step_with_transfer(hank, hank_model):
+    from oracle.oracle import Oracle
+    m, ss = hank_model
+    hb = hank.household_block(m)
+    wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    orc = Oracle(wd.grid, pdm.grid, pdm.transition, m.params.β, m.params.γ, m.params.borrow_cons)
+    rng = np.random.default_rng(2)
+    N = 3
+    xt = np.array([ss.vars["r"], ss.vars["om"], ss.vars["Tr"]])
+    dxt = rng.standard_normal((3, N))
+    dV = 1e-2 * rng.standard_normal(ss.value.shape + (N,))
+    V, dVo, pol, dpol = hb.backward_step_dual(ss.value, dV, xt, dxt)
+    vin = np.concatenate([ss.value[..., None], dV], axis=-1)
+    st, oV, oK = orc.value_function(vin, np.r_[xt[0], dxt[0]], np.r_[xt[1], dxt[1]], N, tr=np.r_[xt[2], dxt[2]])
+    assert st == 0
+    close(V, oV[..., 0]); close(pol, oK[..., 0]); close(dVo, oV[..., 1:]); close(dpol, oK[..., 1:])
+
+
+def test_monetary_shock_converges(hank):
+    from examples.solve_hank import solve
+    out, x, m, ss = solve(80, 3, 60, shock=0.0025)
+    assert out["residual_norm"] < 1e-8
+    # a contractionary shock: the real rate rises, output and inflation fall on impact
+    assert out["impact"]["r"] > 0 or out["impact"]["i"] > 0
+    assert out["impact"]["Y"] < 0 and out["impact"]["infl"] < 0
