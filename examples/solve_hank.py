@@ -4,7 +4,10 @@ sequence as examples/solve_transition.py: YAML -> calibrate the bond supply -> s
 unit-tangent JVPs on the GPU, household family HANK_VF_ONE_ASSET_HANK) -> NewtonRaphsonHANK -> the perfect-foresight
 response to a monetary-policy shock.
 
-    python examples/solve_hank.py [--n-a 1000 --n-e 7 --T 500 --shock 0.0025]"""
+    python examples/solve_hank.py [--n-a 1000 --n-e 7 --T 500 --shock 0.0025]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/solve_hank.py
+        one process per GPU (RCCL): the unit-tangent chunks of the Jacobian assembly are shared out over the ranks and
+        all-gathered; the Newton iteration itself (one tangent per inner step) runs replicated on every rank."""
 import argparse
 import json
 import sys
@@ -62,4 +65,18 @@ if __name__ == "__main__":
     ap.add_argument("--shock", type=float, default=0.0025)
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose)[0]))
+    import os
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+    out = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose and rank == 0)[0]
+    out["n_gpus"] = world
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()

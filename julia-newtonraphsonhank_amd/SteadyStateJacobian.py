@@ -16,7 +16,7 @@ from .GeneralStructures import SequenceModel, vars_of_type
 from .NewtonRaphson import LinearizedFunction
 
 
-def getSteadyStateJacobian(ss, model: SequenceModel, chunk: int = 512, drop_tol: float = 0.0, device_batch: int = 256):
+def getSteadyStateJacobian(ss, model: SequenceModel, chunk: int = 512, drop_tol: float = 0.0, device_batch: int = 256, group=None):
     """n x n sparse Jacobian of F at the constant steady-state path (SteadyStateJacobian.jl:41-65).
     `chunk` unit tangents are pushed per call; only those that move the household inputs (r, w) reach the GPU,
     in device batches padded to `device_batch` so that one tangent workspace serves every call."""
@@ -31,12 +31,10 @@ def getSteadyStateJacobian(ss, model: SequenceModel, chunk: int = 512, drop_tol:
     x_ss = np.tile(np.array([ss.vars[k] for k in endog_keys]), P)
     exog_ss = {k: np.full(P, float(ss.vars[k])) for k in exog_keys}
     lin = LinearizedFunction(x_ss, exog_ss, model, ss, ss)
-    J = np.empty((n, n))
-    for c0 in range(0, n, chunk):
-        c1 = min(n, c0 + chunk)
-        E = np.zeros((n, c1 - c0))
-        E[np.arange(c0, c1), np.arange(c1 - c0)] = 1.0
-        J[:, c0:c1] = lin.jvp(E, pad_to=device_batch)
+    # unit tangents in chunks; under torch.distributed with W > 1 ranks the chunks of a pass are shared out over the
+    # ranks (one GPU each) and all-gathered (parallel.assemble_columns) — every rank ends with the whole matrix
+    from .parallel import assemble_columns
+    J = assemble_columns(lambda E: lin.jvp(E, pad_to=device_batch), n, chunk, group)
     if drop_tol > 0:
         J[np.abs(J) < drop_tol] = 0.0
     return sp.csc_matrix(J)

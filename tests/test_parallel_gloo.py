@@ -39,6 +39,42 @@ def _worker(rank, world, port, N, ret):
         dist.destroy_process_group()
 
 
+def _worker_cols(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hank_amd.parallel import assemble_columns
+        n = 13
+        A = np.random.default_rng(7).standard_normal((n, n))
+        calls = []
+
+        def jvp_block(E):       # a linear stand-in for LinearizedFunction.jvp
+            calls.append(E.shape[1])
+            return A @ E
+
+        J = assemble_columns(jvp_block, n, chunk=3)
+        ret[rank] = (bool(np.array_equal(J, A)), sum(calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_jacobian_columns_assembled_over_two_ranks():
+    """getSteadyStateJacobian's column assembly under torch.distributed: each rank pushes its share of every pass,
+    one all-gather per pass, every rank ends with the whole matrix (ragged last pass included)."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_cols, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] + ret[1][1] == 13 and abs(ret[0][1] - ret[1][1]) <= 2      # the columns were shared out
+
+
 @pytest.mark.parametrize("N", [8, 5])
 def test_sharded_jvp_two_ranks(N):
     ctx = mp.get_context("spawn")
