@@ -71,6 +71,12 @@ def test_odd_sizes_and_nonpow2_batch(hank):
     run_case(hank, 37, 3, 9, 70, "x1", 0.05, check_policies=False)
     run_case(hank, 37, 3, 9, 130, "x1", 0.05, check_policies=False)
     run_case(hank, 50, 2, 100, 130, "x1", 0.8, check_policies=False)
+    run_case(hank, 37, 3, 9, 33, "x1", 0.05, check_policies=False)      # odd and > 32: one direction per lane, 64-lane groups
+
+
+def test_sixteen_productivity_states(hank):
+    """n_e = 16 is the largest block (1024 threads, one wavefront per productivity column)."""
+    run_case(hank, 40, 16, 8, 6, "x1", 0.05)
 
 
 def test_golden_full_pipeline(hank):
