@@ -435,8 +435,8 @@ __global__ void k_reduce_parts(const double *__restrict__ parts, int nb, int N, 
 
 // ---- tangent sweeps ------------------------------------------------------------------------
 // One wavefront per productivity column e: lane = (tangent nl fastest, wealth row rl), so a wave
-// instruction moves RB = 64/NC adjacent rows x NC tangents = one contiguous 512-byte piece of the
-// [e][a][N] state. The n_e x n_e mixing goes through a 64 x n_e LDS tile (conflict-free: the lane
+// instruction moves RB = 64/NC adjacent rows x NC lanes' worth of tangents = one contiguous 512-byte
+// (one direction per lane) or 1-KiB (two per lane) piece of the [e][a][N] state. The n_e x n_e mixing goes through a 64 x n_e LDS tile (conflict-free: the lane
 // is the fastest LDS index). Block = 64*n_e threads.
 // KV virtual rows per column (rows n_a .. n_a+KV-1 of the dD state) hold partial sums of the
 // mass-point row 0 — see k_tan_fwd.
@@ -468,7 +468,7 @@ __global__ void k_tan_out(const double *__restrict__ dagg, int P, int N, double 
 // (terminal value has zero partials, BackwardIteration.jl:85) => only the X half, from zeros.
 // ds ping-pongs between two [e][a][N] buffers that live in L2 / Infinity Cache.
 // RG = row groups per wave: a wave walks RG groups of RB = 64/NC rows with all their loads in
-// flight together (half the waves, twice the bytes in flight each: one residency round at N=32).
+// flight together (the host picks RG per batch width: tan_rg in hank_hip.hip).
 // Tangent lanes are templated on VT = double (one direction per lane) or double2 (two adjacent directions per
 // lane: every state / dpol access is a 16-byte one, half the vector-memory instructions per byte; the memory
 // layout [..][N] is the same, N even). g.N / g.NC count VT elements.
