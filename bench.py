@@ -91,19 +91,37 @@ def cpu_baseline(m, ss, x, Z, budget_s=12.0):
                           "sample": f"{nall} single-tangent JVPs, one per thread at a time, in {elall:.1f} s on {cores} threads"}}
 
 
-def extra_measurements(hb, d_x, P, N, dev):
+def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     """second half of the BASELINE metric ("wall-clock to converged path, Krusell-Smith T=300") on
     configs[1] (500x4), and the JVP rate of a wider tangent batch on the headline grid."""
     import torch
     from examples.solve_transition import solve
     extra = {"converged_path": []}
-    # configs[1]'s grid with a mild shock and with RunMain.jl's Z_t = 1 + 0.8^t, then the headline grid
-    for n_a, n_e, shock in ((500, 4, 0.01), (500, 4, 0.8), (2000, 11, 0.01)):
-        try:
-            res, _ = solve(n_a, n_e, 300, shock)
-        except Exception as e:          # noqa: BLE001 - report, do not kill the bench line
-            res = {"grid": f"{n_a}x{n_e}", "T": 300, "shock": shock, "error": str(e)[:200]}
-        extra["converged_path"].append(res)
+    # two independent N-wide batches in flight (two contexts, two streams): what a Jacobian assembly, whose column
+    # batches do not depend on each other, gets out of the latency-bound per-period launches. Measured first: HIP maps
+    # streams onto a few hardware queues in creation order, and with the contexts the solves below create the two
+    # streams would share one (and serialise).
+    hb2 = hb.clone()
+    torch.cuda.synchronize()
+    hb.set_stream(None)            # both contexts on their own HIP streams for this measurement
+    try:
+        bufs = [(torch.randn(2 * P * N, dtype=torch.float64, device=dev), torch.empty(P, dtype=torch.float64, device=dev),
+                 torch.empty(P * N, dtype=torch.float64, device=dev)) for _ in range(2)]
+        def both():
+            for h_, (dx_, ag_, out_) in zip((hb, hb2), bufs):
+                h_.primal_jvp_dev(d_x.data_ptr(), dx_.data_ptr(), N, ag_.data_ptr(), out_.data_ptr())
+        both(); hb.sync(); hb2.sync()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            both()
+        hb.sync(); hb2.sync()
+        el = (time.perf_counter() - t0) / reps
+        extra["two_batches_in_flight"] = {"tangents": 2 * N, "JVPs_per_s": 2 * N / el, "ms_per_pair": 1e3 * el}
+    finally:
+        hb.sync()
+        hb2.close()
+        hb.set_stream(torch_stream)
     # wider batch on the same context: N = 256 tangents in one dual-sweep pass
     Nw = 256
     d_dx = torch.randn(2 * P * Nw, dtype=torch.float64, device=dev)
@@ -122,26 +140,13 @@ def extra_measurements(hb, d_x, P, N, dev):
     extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el,
                            "k_fused_back_GBs": G8 * (1 + Nw) / (1e-3 * tm["dual_backward"]["ms"] / tm["dual_backward"]["launches"]) / 1e9,
                            "k_fused_fwd_GBs": G8 * (1 + Nw) / (1e-3 * tm["dual_forward"]["ms"] / tm["dual_forward"]["launches"]) / 1e9}
-    # two independent N-wide batches in flight (two contexts, two streams): what a Jacobian assembly, whose column
-    # batches do not depend on each other, gets out of the latency-bound per-period launches
-    hb.jvp_dev(d_dx.data_ptr(), N, d_out.data_ptr())   # shrink the first context's workspace back to N
-    hb2 = hb.clone()
-    try:
-        bufs = [(torch.randn(2 * P * N, dtype=torch.float64, device=dev), torch.empty(P, dtype=torch.float64, device=dev),
-                 torch.empty(P * N, dtype=torch.float64, device=dev)) for _ in range(2)]
-        def both():
-            for h_, (dx_, ag_, out_) in zip((hb, hb2), bufs):
-                h_.primal_jvp_dev(d_x.data_ptr(), dx_.data_ptr(), N, ag_.data_ptr(), out_.data_ptr())
-        both(); hb.sync(); hb2.sync()
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            both()
-        hb.sync(); hb2.sync()
-        el = (time.perf_counter() - t0) / reps
-        extra["two_batches_in_flight"] = {"tangents": 2 * N, "JVPs_per_s": 2 * N / el, "ms_per_pair": 1e3 * el}
-    finally:
-        hb2.close()
+    # configs[1]'s grid with a mild shock and with RunMain.jl's Z_t = 1 + 0.8^t, then the headline grid
+    for n_a, n_e, shock in ((500, 4, 0.01), (500, 4, 0.8), (2000, 11, 0.01)):
+        try:
+            res, _ = solve(n_a, n_e, 300, shock)
+        except Exception as e:          # noqa: BLE001 - report, do not kill the bench line
+            res = {"grid": f"{n_a}x{n_e}", "T": 300, "shock": shock, "error": str(e)[:200]}
+        extra["converged_path"].append(res)
     return extra
 
 
@@ -289,7 +294,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(m, ss, x, Z)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         if not args.no_extra and world == 1:
-            out["extra"] = extra_measurements(hb, d_x, P, N, dev)
+            out["extra"] = extra_measurements(hb, d_x, P, N, dev, stream.cuda_stream)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
