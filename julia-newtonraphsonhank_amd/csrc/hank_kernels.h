@@ -636,7 +636,7 @@ k_fused_back(Consts c, Record R, const double *__restrict__ xhh, int *err, int t
 //     tangent), and its aggregate term uses pol[0, e].
 template <int RG, typename VT, bool SS>
 __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanGeom &g, int t, const VT *__restrict__ dDin, VT *__restrict__ dDout,
-          const VT *__restrict__ dpol, VT *__restrict__ aggpart, int bidx, int bidy, int nbx_total, VT (*sh)[16 * 64], double *Pish) {
+          const VT *__restrict__ dpol, VT *__restrict__ aggpart, int bidx, int bidy, int nbx_total, VT (*sh)[16 * 64], double *Pish, VT *red) {
     const int nthr = 64 * c.n_e;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
@@ -838,12 +838,13 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
         }
     }
     part = vadd(part, pagg);
+    // aggregate of this block: the columns' partials meet in `red` (its own LDS array: no barrier is needed before
+    // writing it), ONE barrier, then wave 0 sums over columns and over the RB row lanes of each tangent
+    red[e * 64 + lane] = part;
     __syncthreads();
-    sh[0][e * 64 + lane] = part;
-    __syncthreads();
-    if (e == 0) {   // sum over columns, then over the RB row lanes of each tangent
-        VT s = sh[0][lane];
-        for (int k = 1; k < c.n_e; k++) s = vadd(s, sh[0][k * 64 + lane]);
+    if (e == 0) {
+        VT s = red[lane];
+        for (int k = 1; k < c.n_e; k++) s = vadd(s, red[k * 64 + lane]);
         for (int off = 32; off >= g.NC; off >>= 1) s = vadd(s, vshfl_xor(s, off));
         if (rl == 0 && nok) aggpart[((size_t)t * nbx_total + bidx) * N + n] = s;
     }
@@ -854,8 +855,9 @@ __global__ void __launch_bounds__(1024)
 k_tan_fwd(Consts c, Record R, TanGeom g, int t, const VT *__restrict__ dDin, VT *__restrict__ dDout,
           const VT *__restrict__ dpol, VT *__restrict__ aggpart) {
     __shared__ VT sh[RG][16 * 64];
+    __shared__ VT red[16 * 64];
     __shared__ double Pish[256];
-    tan_fwd_body<RG, VT, SS>(c, R, g, t, dDin, dDout, dpol, aggpart, blockIdx.x, blockIdx.y, gridDim.x, sh, Pish);
+    tan_fwd_body<RG, VT, SS>(c, R, g, t, dDin, dDout, dpol, aggpart, blockIdx.x, blockIdx.y, gridDim.x, sh, Pish, red);
 }
 
 // the dual-sweep forward launch: blocks [0, nbp) of grid row 0 run the PRIMAL distribution step of
@@ -866,6 +868,7 @@ k_fused_fwd(Consts c, Record R, int tp, int nbp, double *__restrict__ paggpart, 
             const VT *__restrict__ dDin, VT *__restrict__ dDout, const VT *__restrict__ dpol,
             VT *__restrict__ aggpart) {
     __shared__ VT sh[RG][16 * 64];
+    __shared__ VT red[16 * 64];
     __shared__ double Pish[256];
     if ((int)blockIdx.x < nbp) {
         if (blockIdx.y != 0 || tp < 0 || (int)threadIdx.x >= RBP * c.n_e) return;
@@ -873,7 +876,7 @@ k_fused_fwd(Consts c, Record R, int tp, int nbp, double *__restrict__ paggpart, 
         return;
     }
     if (tt < 0) return;
-    tan_fwd_body<RG, VT, SS>(c, R, g, tt, dDin, dDout, dpol, aggpart, blockIdx.x - nbp, blockIdx.y, gridDim.x - nbp, sh, Pish);
+    tan_fwd_body<RG, VT, SS>(c, R, g, tt, dDin, dDout, dpol, aggpart, blockIdx.x - nbp, blockIdx.y, gridDim.x - nbp, sh, Pish, red);
 }
 
 // ---- granular tangent halves (hank_backward_step_dual) ---------------------------------------
