@@ -79,9 +79,22 @@ if __name__ == "__main__":
     ap.add_argument("--permanent", type=float, default=None, metavar="Z_END", help="two-steady-state scenario: Z jumps to Z_END for good")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
+    import os
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:       # under torch.distributed.run: the Jacobian assembly is shared out over the ranks (one GPU each)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
     if a.permanent is not None:
         out = solve_permanent(a.n_a, a.n_e, a.T, a.permanent, verbose=a.verbose)[0]
+    else:
+        out, x = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose)
+    out["n_gpus"] = world
+    if rank == 0:
         print(json.dumps(out))
-        sys.exit(0)
-    out, x = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose)
-    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+

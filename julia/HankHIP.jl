@@ -27,7 +27,12 @@ end
 mutable struct HankCtx
     ptr::Ptr{Cvoid}
     P::Int; G::Int; n_a::Int; n_e::Int
+    hh_rows::Tuple        # names of the xVals rows the native family reads, in the order the library expects
 end
+
+# native kernel families by value-function name: id (include/hank_hip.h) and the household inputs it reads
+const _FAMILIES = Dict(:ValueFunction => (0, (:r, :w)),                # KrusellSmith.jl:43-83, :53-54
+                       :HANKValueFunction => (1, (:r, :om, :Tr)))      # one-asset HANK (not in the reference)
 
 const _CTX = IdDict{Any,HankCtx}()     # one device context per SequenceModel
 
@@ -41,28 +46,29 @@ function hank_context(model::SequenceModel)
     get!(_CTX, model) do
         w = model.heterogeneity.wealth; p = model.heterogeneity.productivity
         a = collect(Float64, w.grid); z = collect(Float64, p.grid); Π = Matrix{Float64}(p.transition)
-        # only "ValueFunction" (KrusellSmith.jl:43-83) has a native kernel family so far
-        nameof(model.value_fn) == :ValueFunction || error("no native kernel family for $(model.value_fn)")
+        haskey(_FAMILIES, nameof(model.value_fn)) || error("no native kernel family for $(model.value_fn)")
+        fam_id, rows = _FAMILIES[nameof(model.value_fn)]
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         GC.@preserve a z Π begin
-            m = HankModelC(w.n, p.n, model.compspec.T, 0, pointer(a), pointer(z), pointer(Π),
+            m = HankModelC(w.n, p.n, model.compspec.T, fam_id, pointer(a), pointer(z), pointer(Π),
                            model.params.β, model.params.γ, model.params.borrow_cons)
             rc = ccall((:hank_create, LIBHANK), Cint, (Ref{HankModelC}, Ref{Ptr{Cvoid}}), m, ref)
         end
         _check(ref[], rc)
-        ctx = HankCtx(ref[], model.compspec.T - 1, w.n * p.n, w.n, p.n)
+        ctx = HankCtx(ref[], model.compspec.T - 1, w.n * p.n, w.n, p.n, rows)
+        @assert ccall((:hank_n_hh, LIBHANK), Cint, (Ptr{Cvoid},), ref[]) == length(rows)
         finalizer(c -> ccall((:hank_destroy, LIBHANK), Cint, (Ptr{Cvoid},), c.ptr), ctx)
         ctx
     end
 end
 
-# rows of xVals the KS value function reads (KrusellSmith.jl:53-54): r_t, w_t
+# rows of xVals the value function reads (KS: r_t, w_t, KrusellSmith.jl:53-54)
 function _household_inputs(xVec_endog, model)
     @unpack T, n_endog = model.compspec
     xMat = reshape(xVec_endog, n_endog, T - 1)
     ek = vars_of_type(model, :endogenous)
-    rows = [findfirst(==(k), ek) for k in (:r, :w)]
-    return xMat[rows, :]                                      # 2 x (T-1), eltype of x
+    rows = [findfirst(==(k), ek) for k in hank_context(model).hh_rows]
+    return xMat[rows, :]                                      # n_hh x (T-1), eltype of x
 end
 
 # What BackwardIteration returns: the reference's NamedTuple-of-Vector{Matrix} surface (seqs.KD[t]),
@@ -96,7 +102,7 @@ function BackwardIteration(xVec_endog, exog_paths::NamedTuple, model::SequenceMo
     xd = _household_inputs(xVec_endog, model)
     xhh = Matrix{Float64}(value.(xd))
     N = TF <: Dual ? length(partials(first(xVec_endog))) : 0
-    dxhh = N > 0 ? Float64[partials(xd[k, t])[n] for k in 1:2, t in 1:ctx.P, n in 1:N] : nothing   # (n_hh, P, N)
+    dxhh = N > 0 ? Float64[partials(xd[k, t])[n] for k in 1:size(xd, 1), t in 1:ctx.P, n in 1:N] : nothing   # (n_hh, P, N)
     D0 = ss_initial === nothing ? fill(1.0 / ctx.G, ctx.G) : Vector{Float64}(ss_initial.D)
     val = Matrix{Float64}(ss_end.value)
     agg, dagg = _run_block(ctx, val, D0, xhh, dxhh)
