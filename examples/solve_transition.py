@@ -23,6 +23,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False):
     import hank_amd as h
+    import hank_amd.parallel  # noqa: F401  (pulls in torch before the clocks start)
     from conftest import ks_setup
     t0 = time.perf_counter()
     m, ss, _ = ks_setup(n_a, n_e, T)
@@ -50,6 +51,7 @@ def solve_permanent(n_a=200, n_e=3, T=150, Z_end=1.03, eps=1e-9, verbose=False):
     value is the ending steady state's (BackwardIteration.jl:85), Newton starts at the ending steady state repeated and
     uses the sequence-space Jacobian there."""
     import hank_amd as h
+    import hank_amd.parallel  # noqa: F401
     ov = {"T": T, "dimensions": {"wealth": {"n": n_a}, "productivity": {"n": n_e}},
           "steady_states": {"ending": {"fixed": {"Z": Z_end}, "guesses": {"r": 0.04, "w": 1.0, "Y": 1.5, "KS": 3.5}}}}
     m = h.build_model_from_yaml(str(ROOT / "examples" / "krusell_smith.yaml"), overrides=ov)
