@@ -57,20 +57,40 @@ def household_inputs(xVec_endog, exog_paths, model: SequenceModel):
 
 class PolicySequences(dict):
     """BackwardIteration's return value: {het_var: list of P (n_a x n_e) matrices}; the matrices are
-    fetched from HBM lazily. Carries the tag ForwardIteration uses to stay on the fused path."""
+    fetched from HBM lazily. Carries the tag ForwardIteration uses to stay on the fused path.
 
-    def __init__(self, hb, het_keys, is_dual, N, D_used, generation):
+    The reference's 4-argument call (NewtonRaphson.jl:78) does not know `ss_initial`, and the fused device
+    sweep needs D_0: such a call is DEFERRED — nothing runs until ForwardIteration supplies `ss_initial`
+    (one sweep in all, NewtonRaphson.jl:78-79) or until a policy matrix is actually read (then the sweep runs
+    with a placeholder D_0; policies do not depend on it)."""
+
+    def __init__(self, hb, het_keys, is_dual, N, pending):
         super().__init__()
         self._hb, self._het_keys, self._is_dual, self._N = hb, het_keys, is_dual, N
-        self._D_used, self._generation = D_used, generation
+        self._pending = pending            # {"xhh", "dxhh", "value"} until the device sweep has run
+        self._D_used, self._generation = None, None
         self._fetched = False
         for k in het_keys:
             dict.__setitem__(self, k, None)
+
+    def _run(self, D0):
+        """the ONE fused device sweep of this BackwardIteration (+ ForwardIteration) pair."""
+        hb, pend = self._hb, self._pending
+        hb.set_boundary(pend["value"], D0)
+        if pend["dxhh"] is not None:      # a Dual pass carries value and partials together, like the reference's JVP
+            agg, dagg = hb.primal_jvp(pend["xhh"], pend["dxhh"])
+        else:
+            agg, dagg = hb.primal(pend["xhh"]), None
+        hb._generation = getattr(hb, "_generation", 0) + 1
+        hb._last = {"agg": agg, "dagg": dagg, "D0": D0, "xhh": pend["xhh"], "dxhh": pend["dxhh"], "value": pend["value"]}
+        self._D_used, self._generation, self._pending = D0, hb._generation, None
 
     def _fetch(self):
         if self._fetched:
             return
         hb = self._hb
+        if self._pending is not None:
+            self._run(np.full(hb.G, 1.0 / hb.G))
         if getattr(hb, "_generation", None) != self._generation:
             raise RuntimeError("policy sequences were overwritten by a later BackwardIteration on this model")
         pol = hb.policy_seq()                      # (n_a, n_e, P)
@@ -99,9 +119,8 @@ class PolicySequences(dict):
 def BackwardIteration(xVec_endog, exog_paths, model: SequenceModel, ss_end, ss_initial=None):
     """Backward iteration over the T-1 transition periods (BackwardIteration.jl:46-116).
 
-    `ss_initial` (optional, not in the reference signature) lets the fused device sweep use the
-    right initial distribution straight away, so a following ForwardIteration on the returned
-    sequences costs nothing extra."""
+    With the reference's four arguments the device sweep is deferred to ForwardIteration (see
+    PolicySequences); `ss_initial` (optional, not in the reference signature) runs it here instead."""
     cs = model.compspec
     P = cs.T - 1
     n = (xVec_endog.v if isinstance(xVec_endog, Dual) else np.asarray(xVec_endog)).size
@@ -113,13 +132,12 @@ def BackwardIteration(xVec_endog, exog_paths, model: SequenceModel, ss_end, ss_i
             raise KeyError(f"BackwardIteration: value_fn return is missing key :{k} (got keys: {model.value_fn.outputs})")
     hb = household_block(model)
     xhh, dxhh = household_inputs(xVec_endog, exog_paths, model)
-    D0 = np.asarray(ss_initial.D, dtype=np.float64) if ss_initial is not None else np.full(hb.G, 1.0 / hb.G)
-    hb.set_boundary(ss_end.value, D0)
-    if dxhh is not None:      # a Dual pass carries value and partials together, like the reference's JVP
-        agg, dagg = hb.primal_jvp(xhh, dxhh)
-    else:
-        agg, dagg = hb.primal(xhh), None
-    hb._generation = getattr(hb, "_generation", 0) + 1
-    hb._last = {"agg": agg, "dagg": dagg, "D0": D0, "xhh": xhh, "dxhh": dxhh,
-                "value": np.array(ss_end.value, dtype=np.float64, copy=True)}
-    return PolicySequences(hb, het_keys, dxhh is not None, 0 if dxhh is None else dxhh.shape[2], D0, hb._generation)
+    if model.value_fn.household_inputs[0] == "r" and not np.all(1.0 + xhh[0] > 0.0):   # raised here, not at the deferred sweep
+        bad = int(np.flatnonzero(~(1.0 + xhh[0] > 0.0))[0]) + 1
+        from .hip import DomainError, HANK_ERR_DOMAIN
+        raise DomainError(HANK_ERR_DOMAIN, f"1 + r must be positive (period {bad})")
+    seqs = PolicySequences(hb, het_keys, dxhh is not None, 0 if dxhh is None else dxhh.shape[2],
+                           {"xhh": xhh, "dxhh": dxhh, "value": np.array(ss_end.value, dtype=np.float64, copy=True)})
+    if ss_initial is not None:
+        seqs._run(np.asarray(ss_initial.D, dtype=np.float64))
+    return seqs

@@ -61,7 +61,14 @@ def ForwardIteration(policy_seqs, model: SequenceModel, ss_initial):
     hb = household_block(model)
     D0 = np.asarray(ss_initial.D, dtype=np.float64)
 
-    if isinstance(policy_seqs, PolicySequences) and getattr(hb, "_generation", None) == policy_seqs._generation:
+    pol_key = endog[0][1].policy_var
+    if isinstance(policy_seqs, PolicySequences) and policy_seqs._pending is not None and tuple(het_keys) == (pol_key,):
+        policy_seqs._run(D0)         # the deferred sweep of a 4-argument BackwardIteration: ONE pass, with the right D_0
+    if isinstance(policy_seqs, PolicySequences) and getattr(hb, "_generation", None) == policy_seqs._generation \
+            and tuple(het_keys) == (pol_key,) and getattr(hb, "_last", None) is not None:
+        # fused path: the device sweep aggregates the policy variable with its own policy; a family with a second
+        # heterogeneous variable must take the generic path below (ForwardIteration.jl:303-305 aggregates each
+        # variable with ITS policy)
         last = hb._last
         if not np.array_equal(last["D0"], D0):
             # the backward sweep did not know ss_initial: redo the fused sweep with the right D_0
@@ -74,7 +81,6 @@ def ForwardIteration(policy_seqs, model: SequenceModel, ss_initial):
         return {k: out for k in het_keys}
 
     # generic path: explicit policy matrices, one granular device step per period
-    pol_key = endog[0][1].policy_var
     seqs = {k: policy_seqs[k] for k in het_keys}
     first = seqs[het_keys[0]][0]
     is_dual = isinstance(first, Dual)

@@ -40,12 +40,23 @@ class LinearizedFunction:
         self.mod, self.exog_paths, self.ss_initial, self.ss_ending = mod, exog_paths, ss_initial, ss_ending
         self.hb = household_block(mod)
         xhh, _ = household_inputs(self.x, exog_paths, mod)
-        self.hb.set_boundary(ss_ending.value, ss_initial.D)
-        self.agg = self.hb.primal(xhh)
+        self._xhh = xhh
+        self._record_primal()
         het = vars_of_type(mod, "heterogeneous")
         self.het = het
         self.Fx = Residuals(assemble_full_xMat(self.x, {k: self.agg for k in het}, exog_paths, mod,
                                                ss_initial, ss_ending), mod)
+
+    def _record_primal(self):
+        """(re-)run the Float64 sweep at x on the model's device context and take ownership of its record: the
+        context is shared by everything that touches this model, so the generation counter says whose primal
+        it currently holds (BackwardIteration and other linearisations bump it too)."""
+        hb = self.hb
+        hb.set_boundary(self.ss_ending.value, self.ss_initial.D)
+        self.agg = hb.primal(self._xhh)
+        hb._generation = getattr(hb, "_generation", 0) + 1
+        hb._last = None          # an older PolicySequences must not take ForwardIteration's fused shortcut
+        self._generation = hb._generation
 
     def jvp(self, y, pad_to: int | None = None):
         """J(x)·y for one tangent (n,) or a batch (n, N). Directions that do not move the household inputs
@@ -62,6 +73,11 @@ class LinearizedFunction:
         nz = np.flatnonzero(np.any(dxhh != 0.0, axis=(0, 1)))
         dagg = np.zeros((dxhh.shape[1], N))
         if len(nz):
+            if getattr(self.hb, "_generation", None) != self._generation:
+                # another linearisation / BackwardIteration used the model's context since: its record is not
+                # this x's any more — restore ours (bit-identical: same kernels, same inputs) instead of
+                # silently returning J(x_other)·y
+                self._record_primal()
             sub = dxhh[:, :, nz]
             if pad_to and len(nz) % pad_to:
                 padded = np.zeros(sub.shape[:2] + (-(-len(nz) // pad_to) * pad_to,))
@@ -84,21 +100,19 @@ def _gmres(J, b, x0):
     return x
 
 
-_LU_CACHE = {}
+_LU_CACHE = []          # [(J, lu)]: holds the factored matrix itself — an id() alone can be recycled by a new J̅
 
 
 def _lu_solver(J):
     """J̅ obtained from batched JVPs is a dense n x n matrix (n ≈ 1.2k): one LU factorisation, reused
     by every inner and outer iteration, replaces the two GMRES solves per inner iteration — same
-    J̅⁻¹·b up to rounding, milliseconds instead of seconds on the host."""
-    key = id(J)
-    if key not in _LU_CACHE:
-        import scipy.linalg as sla
-        _LU_CACHE.clear()
-        A = J.toarray() if hasattr(J, "toarray") else np.asarray(J)
-        _LU_CACHE[key] = sla.lu_factor(A)
-    lu = _LU_CACHE[key]
+    J̅⁻¹·b up to rounding, milliseconds instead of seconds on the host. (A deviation from
+    NewtonRaphson.jl:97-98, which runs two warm-started gmres! solves: `linear_solver="gmres"` is that branch.)"""
     import scipy.linalg as sla
+    if not (_LU_CACHE and _LU_CACHE[0][0] is J):
+        A = J.toarray() if hasattr(J, "toarray") else np.asarray(J)
+        _LU_CACHE[:] = [(J, sla.lu_factor(A))]
+    lu = _LU_CACHE[0][1]
     return lambda b: sla.lu_solve(lu, b)
 
 
@@ -122,7 +136,8 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
         else:
             R = _gmres(J̅, Fx - Λxy, R)
             M = _gmres(J̅, Λxy, M)
-        ray = float(y @ M) / float(y @ y)
+        with np.errstate(divide="ignore", invalid="ignore"):      # printed only (:101, :108-110); NaN at y = 0 like Julia
+            ray = np.divide(y @ M, y @ y) if verbose else np.nan
         α = 0.5
         y_old = y
         y = y_old + α * R

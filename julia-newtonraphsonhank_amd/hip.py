@@ -146,6 +146,8 @@ class HouseholdBlock:
                 self._ctx = C.c_void_p()
             raise _ERR_CLASSES.get(rc, HankHIPError)(rc, msg or "no HIP device available (gfx950 required)")
         self.n_hh = self._lib.hank_n_hh(self._ctx)
+        # sweeps issued through this context, by entry point (tests assert "ONE sweep per fullFunction")
+        self.calls = {"primal": 0, "jvp": 0, "primal_jvp": 0}
 
     # -- plumbing ---------------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -191,6 +193,7 @@ class HouseholdBlock:
     def primal(self, xhh) -> np.ndarray:
         x = _f(xhh, (self.n_hh, self.P))
         agg = np.empty(self.P)
+        self.calls["primal"] += 1
         self._chk(self._lib.hank_primal(self._ctx, _p(x), _p(agg)))
         return agg
 
@@ -201,6 +204,7 @@ class HouseholdBlock:
         N = dx.shape[2]
         dx = _f(dx, (self.n_hh, self.P, N))
         out = np.empty((self.P, N), order="F")
+        self.calls["jvp"] += 1
         self._chk(self._lib.hank_jvp(self._ctx, _p(dx), N, _p(out)))
         return out
 
@@ -214,6 +218,7 @@ class HouseholdBlock:
         dx = _f(dx, (self.n_hh, self.P, N))
         agg = np.empty(self.P)
         dagg = np.empty((self.P, N), order="F")
+        self.calls["primal_jvp"] += 1
         self._chk(self._lib.hank_primal_jvp(self._ctx, _p(x), _p(dx), N, _p(agg), _p(dagg)))
         return agg, dagg
 

@@ -14,7 +14,7 @@
 # x::Vector{ForwardDiff.Dual{T,Float64,N}} the N partials travel as one tangent batch (hank_jvp), so
 # `JVP(fullFunction, x, y)` (GeneralStructures.jl:542-550) and ForwardDiff.jacobian chunks work unchanged.
 
-using ForwardDiff: Dual, value, partials
+using ForwardDiff: Dual, Partials, value, partials, tagtype
 
 const LIBHANK = get(ENV, "HANK_HIP_LIB", joinpath(@__DIR__, "..", "julia-newtonraphsonhank_amd", "libhank_hip.so"))
 
@@ -72,30 +72,39 @@ function _household_inputs(xVec_endog, model)
 end
 
 # What BackwardIteration returns: the reference's NamedTuple-of-Vector{Matrix} surface (seqs.KD[t]),
-# copied from HBM on demand, plus what the fused sweep already knows (so ForwardIteration is free).
-struct DevicePolicySeqs{TF}
+# copied from HBM on demand. The reference calls BackwardIteration with FOUR positionals
+# (NewtonRaphson.jl:78) — `ss_initial` only reaches ForwardIteration (:79) — and the fused device sweep
+# needs D_0, so the device call is DEFERRED: ForwardIteration runs the one fused sweep; reading a policy
+# matrix before that runs it with a placeholder D_0 (policies do not depend on D_0).
+mutable struct DevicePolicySeqs{TF}
     ctx::HankCtx; het_keys::Tuple; N::Int
     xhh::Matrix{Float64}; dxhh::Union{Nothing,Array{Float64,3}}; value::Matrix{Float64}
-    D0::Vector{Float64}; agg::Vector{Float64}; dagg::Union{Nothing,Matrix{Float64}}
+    D0::Union{Nothing,Vector{Float64}}; agg::Union{Nothing,Vector{Float64}}; dagg::Union{Nothing,Matrix{Float64}}
 end
 
-function _run_block(ctx::HankCtx, value, D0, xhh, dxhh)
-    _check(ctx.ptr, ccall((:hank_set_boundary, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, value, D0))
+# a Dual of the caller's own type TF = Dual{Tag,Float64,N} from a value and N partials: the inner
+# constructor takes a Partials (ForwardDiff.jl/src/dual.jl:14-21); Dual{Tag}(v, ::Partials) is the
+# public form (:59-66). There is no TF(value, p1, ..., pN) method.
+@inline _mkdual(::Type{TF}, v::Float64, p::NTuple{N,Float64}) where {N,TF<:Dual} = Dual{tagtype(TF)}(v, Partials(p))
+
+function _run_block!(s::DevicePolicySeqs, D0::Vector{Float64})
+    ctx = s.ctx
+    _check(ctx.ptr, ccall((:hank_set_boundary, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, s.value, D0))
     agg = Vector{Float64}(undef, ctx.P)
     dagg = nothing
-    if dxhh === nothing
-        _check(ctx.ptr, ccall((:hank_primal, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, xhh, agg))
+    if s.dxhh === nothing
+        _check(ctx.ptr, ccall((:hank_primal, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, s.xhh, agg))
     else      # a Dual pass carries value and partials together (NewtonRaphson.jl:95): one dual-sweep call
-        N = size(dxhh, 3)
-        dagg = Matrix{Float64}(undef, ctx.P, N)
+        dagg = Matrix{Float64}(undef, ctx.P, s.N)
         _check(ctx.ptr, ccall((:hank_primal_jvp, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}),
-                              ctx.ptr, xhh, dxhh, N, agg, dagg))
+                              ctx.ptr, s.xhh, s.dxhh, s.N, agg, dagg))
     end
-    return agg, dagg
+    s.D0, s.agg, s.dagg = D0, agg, dagg
+    return s
 end
 
-# same positional signature as BackwardIteration.jl:46-49; `ss_initial` (optional) lets the fused sweep
-# use the right D_0 straight away so that the following ForwardIteration costs nothing.
+# same positional signature as BackwardIteration.jl:46-49. No device work happens here (see above);
+# `ss_initial` (optional keyword, not in the reference) runs the fused sweep straight away.
 function BackwardIteration(xVec_endog, exog_paths::NamedTuple, model::SequenceModel, ss_end; ss_initial = nothing)
     ctx = hank_context(model)
     TF = eltype(xVec_endog)
@@ -103,31 +112,32 @@ function BackwardIteration(xVec_endog, exog_paths::NamedTuple, model::SequenceMo
     xhh = Matrix{Float64}(value.(xd))
     N = TF <: Dual ? length(partials(first(xVec_endog))) : 0
     dxhh = N > 0 ? Float64[partials(xd[k, t])[n] for k in 1:size(xd, 1), t in 1:ctx.P, n in 1:N] : nothing   # (n_hh, P, N)
-    D0 = ss_initial === nothing ? fill(1.0 / ctx.G, ctx.G) : Vector{Float64}(ss_initial.D)
-    val = Matrix{Float64}(ss_end.value)
-    agg, dagg = _run_block(ctx, val, D0, xhh, dxhh)
-    return DevicePolicySeqs{TF}(ctx, vars_of_type(model, :heterogeneous), N, xhh, dxhh, val, D0, agg, dagg)
+    s = DevicePolicySeqs{TF}(ctx, vars_of_type(model, :heterogeneous), N, xhh, dxhh, Matrix{Float64}(ss_end.value),
+                             nothing, nothing, nothing)
+    ss_initial === nothing || _run_block!(s, Vector{Float64}(ss_initial.D))
+    return s
 end
 
 # seqs.KD -> Vector of T-1 (Dual) matrices, as in the reference (BackwardIteration.jl:110-115)
 function Base.getproperty(s::DevicePolicySeqs{TF}, k::Symbol) where {TF}
     k in fieldnames(DevicePolicySeqs) && return getfield(s, k)
     ctx = getfield(s, :ctx); N = getfield(s, :N)
+    getfield(s, :agg) === nothing && _run_block!(s, fill(1.0 / ctx.G, ctx.G))     # read before ForwardIteration
     pol = Array{Float64}(undef, ctx.n_a, ctx.n_e, ctx.P)
     _check(ctx.ptr, ccall((:hank_get_policy_seq, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.ptr, pol))
     N == 0 && return [pol[:, :, t] for t in 1:ctx.P]
     dpol = Array{Float64}(undef, ctx.n_a, ctx.n_e, ctx.P, N)
     _check(ctx.ptr, ccall((:hank_get_dpolicy_seq, LIBHANK), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ctx.ptr, N, dpol))
-    return [[TF(pol[a, e, t], ntuple(n -> dpol[a, e, t, n], N)...) for a in 1:ctx.n_a, e in 1:ctx.n_e] for t in 1:ctx.P]
+    return [[_mkdual(TF, pol[a, e, t], ntuple(n -> dpol[a, e, t, n], N)) for a in 1:ctx.n_a, e in 1:ctx.n_e] for t in 1:ctx.P]
 end
 
-# same signature as ForwardIteration.jl:253-255 for sequences that came from BackwardIteration above
+# same signature as ForwardIteration.jl:253-255 for sequences that came from BackwardIteration above:
+# this is where the ONE fused sweep of a fullFunction evaluation runs (NewtonRaphson.jl:78-79)
 function ForwardIteration(seqs::DevicePolicySeqs{TF}, model::SequenceModel, ss_initial) where {TF}
+    length(seqs.het_keys) == 1 || error("the fused device sweep aggregates one heterogeneous variable (got $(seqs.het_keys))")
     D0 = Vector{Float64}(ss_initial.D)
+    (seqs.agg === nothing || D0 != seqs.D0) && _run_block!(seqs, D0)
     agg, dagg = seqs.agg, seqs.dagg
-    if D0 != seqs.D0      # the backward call did not know ss_initial: redo the fused sweep with the right D_0
-        agg, dagg = _run_block(seqs.ctx, seqs.value, D0, seqs.xhh, seqs.dxhh)
-    end
-    out = seqs.N == 0 ? agg : [TF(agg[t], ntuple(n -> dagg[t, n], seqs.N)...) for t in 1:length(agg)]
-    return NamedTuple{seqs.het_keys}(ntuple(_ -> out, length(seqs.het_keys)))
+    out = seqs.N == 0 ? agg : [_mkdual(TF, agg[t], ntuple(n -> dagg[t, n], seqs.N)) for t in 1:length(agg)]
+    return NamedTuple{seqs.het_keys}((out,))
 end

@@ -101,3 +101,73 @@ def test_permanent_shock_between_two_steady_states(hank):
     assert abs(KS[0] - ss_i.vars["KS"]) < 0.2 * (ss_e.vars["KS"] - ss_i.vars["KS"])
     assert np.all(np.diff(KS) > -1e-9)
     assert abs(KS[-1] - ss_e.vars["KS"]) < 2e-3 * ss_e.vars["KS"]
+
+
+def test_four_argument_backward_iteration_issues_one_sweep(hank):
+    """the reference's own call pair (NewtonRaphson.jl:78-79): BackwardIteration with FOUR positionals, then
+    ForwardIteration — ONE fused device sweep in all (the device call is deferred until ss_initial is known), for a
+    Float64 pass and for a Dual pass; reading a policy matrix first still works (placeholder D_0, then one redo)."""
+    m, ss, orc = ks_setup(50, 2, 100)
+    P = 99
+    x, Z = ks_paths(m, ss, "x1", 0.05)
+    xv = x.reshape(-1, order="F")
+    hb = hank.household_block(m)
+    before = dict(hb.calls)
+    seqs = hank.BackwardIteration(xv, {"Z": Z}, m, ss)
+    assert hb.calls == before                                   # nothing ran yet
+    agg = hank.ForwardIteration(seqs, m, ss)["KD"]
+    assert hb.calls["primal"] == before["primal"] + 1 and hb.calls["jvp"] == before["jvp"] and hb.calls["primal_jvp"] == before["primal_jvp"]
+    assert len(seqs["KD"]) == P                                 # the record is still this call's: no new sweep
+    assert hb.calls["primal"] == before["primal"] + 1
+    y = np.random.default_rng(3).standard_normal((4 * P, 2))
+    xd = hank.Dual.seed(xv, y)
+    before = dict(hb.calls)
+    dseqs = hank.BackwardIteration(xd, {"Z": Z}, m, ss)
+    dagg = hank.ForwardIteration(dseqs, m, ss)["KD"]
+    assert hb.calls == {"primal": before["primal"], "jvp": before["jvp"], "primal_jvp": before["primal_jvp"] + 1}
+    assert np.array_equal(dagg.v, agg)
+    # the five-argument form gives the same numbers
+    ref = hank.ForwardIteration(hank.BackwardIteration(xd, {"Z": Z}, m, ss, ss_initial=ss), m, ss)["KD"]
+    assert np.array_equal(ref.v, dagg.v) and np.array_equal(ref.p, dagg.p)
+    # policies read BEFORE ForwardIteration: sweep with a placeholder D_0, redone once with the right one
+    s2 = hank.BackwardIteration(xv, {"Z": Z}, m, ss)
+    pol_first = np.array(s2["KD"][0])
+    agg2 = hank.ForwardIteration(s2, m, ss)["KD"]
+    assert np.array_equal(agg2, agg) and np.array_equal(pol_first, seqs["KD"][0])
+
+
+def test_two_live_linearisations_do_not_mix(hank):
+    """two LinearizedFunction objects at different x share the model's device context: a jvp on the older one must
+    not silently use the newer one's record (it restores its own primal first)."""
+    m, ss, orc = ks_setup(50, 2, 100)
+    P = 99
+    xa, Z = ks_paths(m, ss, "x1", 0.05)
+    xb, _ = ks_paths(m, ss, "x1", 0.3)
+    y = np.random.default_rng(4).standard_normal(4 * P)
+    la = hank.LinearizedFunction(xa.reshape(-1, order="F"), {"Z": Z}, m, ss, ss)
+    ja = la.jvp(y)
+    lb = hank.LinearizedFunction(xb.reshape(-1, order="F"), {"Z": Z}, m, ss, ss)
+    jb = lb.jvp(y)
+    assert np.max(np.abs(ja - jb)) > 1e-6                       # genuinely different linearisations
+    assert np.array_equal(la.jvp(y), ja)                        # la re-records its own primal
+    assert np.array_equal(lb.jvp(y), jb)
+    _, J_o = orc.ks_jvp(xa, y.reshape(4, P, 1, order="F"), Z, m.params.α, m.params.δ, ss.vars["KS"], ss.value, ss.D)
+    assert np.max(np.abs(la.jvp(y) - J_o[:, 0])) < 1e-10 * np.abs(J_o).max()
+
+
+def test_newton_with_the_reference_gmres_inner_solves(hank):
+    """the faithful inner loop (NewtonRaphson.jl:97-98: two warm-started restarted GMRES solves per inner iteration,
+    IterativeSolvers defaults restart = min(20, n), reltol = sqrt(eps)) reaches the same converged path as the
+    LU branch this package defaults to, within 1e-8."""
+    m, ss, orc = ks_setup(50, 2, 60)
+    P = 59
+    Z = 1.0 + 0.01 * 0.8 ** np.arange(1, P + 1)
+    J = hank.getSteadyStateJacobian(ss, m)
+    x0, _ = ks_paths(m, ss, "x0")
+    x_lu = hank.NewtonRaphsonHANK(x0.reshape(-1, order="F"), J, {"Z": Z}, m, ss, ss, ε=1e-9)
+    it_lu = hank.NewtonRaphsonHANK.iterations
+    x_gm = hank.NewtonRaphsonHANK(x0.reshape(-1, order="F"), J, {"Z": Z}, m, ss, ss, ε=1e-9, linear_solver="gmres")
+    assert np.max(np.abs(x_gm - x_lu)) < 1e-8
+    lin = hank.LinearizedFunction(x_gm, {"Z": Z}, m, ss, ss)
+    assert np.linalg.norm(lin.Fx) < 1e-8
+    assert hank.NewtonRaphsonHANK.iterations <= it_lu + 3

@@ -61,3 +61,76 @@ def test_finite_difference_of_the_device_primal(big):
     hb.primal(x[2:4])
     fd = (up - dn) / (2 * h)
     assert np.max(np.abs(fd - dagg[:, 3])) < 5e-4 * np.abs(dagg[:, 3]).max()
+
+
+def _oracle_cols(orc, x, y, cols, ss, xt=None, yt=None):
+    """value + the tangent columns `cols` through the CPU oracle (r, w[, transfer] duals)."""
+    P, N = y.shape[1], len(cols)
+    xr = np.zeros((P, 1 + N)); xw = np.zeros((P, 1 + N))
+    xr[:, 0], xw[:, 0] = x[0], x[1]
+    xr[:, 1:], xw[:, 1:] = y[0][:, cols], y[1][:, cols]
+    xtd = None
+    if xt is not None:
+        xtd = np.zeros((P, 1 + N)); xtd[:, 0] = xt; xtd[:, 1:] = yt[:, cols]
+    st, oagg, _ = orc.household_block(xr, xw, ss.value, ss.D, N, xt=xtd)
+    assert st == 0
+    return oagg
+
+
+def test_benched_entry_primal_jvp_N32(big):
+    """the entry point bench.py times (hank_primal_jvp: value and 32 partials in one dual pass) at the benched size:
+    same numbers as hank_primal + hank_jvp, and two of its columns against the oracle (NewtonRaphson.jl:95)."""
+    m, ss, orc, hb, x, Z, y, agg, dagg = big
+    agg2, dagg2 = hb.primal_jvp(x[2:4], y)
+    assert np.array_equal(agg2, agg) and np.array_equal(dagg2, dagg)
+    oagg = _oracle_cols(orc, x[2:4], y, [5, 18], ss)
+    assert np.max(np.abs(agg2 - oagg[:, 0])) < 1e-10 * np.abs(oagg[:, 0]).max()
+    assert np.max(np.abs(dagg2[:, [5, 18]] - oagg[:, 1:])) < 1e-12 + 1e-10 * np.abs(oagg[:, 1:]).max()
+    assert np.array_equal(hb.jvp(y), dagg)            # the record it leaves serves later JVPs
+
+
+def test_wide_batch_N256_full_size(big):
+    """configs[3]'s per-node batch (256 tangents) on one GPU at 2000x11, T=300: two columns against the oracle,
+    linearity in the tangent, bitwise repeatability, and batch invariance against the N=32 result."""
+    m, ss, orc, hb, x, Z, y, agg, dagg = big
+    N = 256
+    yw = np.random.default_rng(7).standard_normal((2, 299, N))
+    yw[:, :, :32] = y                                  # the first 32 columns are the N=32 batch
+    aggw, daggw = hb.primal_jvp(x[2:4], yw)
+    assert np.array_equal(aggw, agg)
+    scale = np.abs(dagg).max()
+    assert np.max(np.abs(daggw[:, :32] - dagg)) < 1e-12 + 1e-11 * scale      # same directions in another batch geometry
+    oagg = _oracle_cols(orc, x[2:4], yw, [100, 255], ss)
+    assert np.max(np.abs(daggw[:, [100, 255]] - oagg[:, 1:])) < 1e-12 + 1e-10 * np.abs(oagg[:, 1:]).max()
+    c = np.random.default_rng(8).standard_normal(N)
+    comb = hb.jvp(np.tensordot(yw, c, axes=([2], [0]))[:, :, None])[:, 0]
+    assert np.max(np.abs(comb - daggw @ c)) < 1e-9 * np.abs(daggw @ c).max()
+    again = hb.jvp(yw)
+    assert np.array_equal(again, daggw)
+    hb.primal(x[2:4]); hb.jvp(y)                       # leave the module fixture's state behind
+
+
+def test_config4_hank_1000x7_T500():
+    """BASELINE.json configs[4] at its stated size on one GPU: one-asset HANK 1000x7, T=500 — hank_primal_jvp with 32
+    tangents, two columns against the oracle's restatement of the same family (parity unpinned by construction:
+    the family is not in the reference), plus the split schedule."""
+    import hank_amd as h
+    from examples.solve_hank import build
+    from oracle.oracle import Oracle
+    m, ss = build(1000, 7, 500)
+    P, N = 499, 32
+    rng = np.random.default_rng(11)
+    t = np.arange(P)
+    x = np.stack([ss.vars["r"] + 0.002 * 0.8 ** t, ss.vars["om"] * (1 + 0.01 * 0.7 ** t), ss.vars["Tr"] * (1 - 0.02 * 0.9 ** t)])
+    y = rng.standard_normal((3, P, N))
+    hb = h.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    agg, dagg = hb.primal_jvp(x, y)
+    wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    orc = Oracle(wd.grid, pdm.grid, pdm.transition, m.params.β, m.params.γ, m.params.borrow_cons)
+    oagg = _oracle_cols(orc, x[:2], y[:2], [0, 31], ss, xt=x[2], yt=y[2])
+    assert np.max(np.abs(agg - oagg[:, 0])) < 1e-10 * np.abs(oagg[:, 0]).max()
+    assert np.max(np.abs(dagg[:, [0, 31]] - oagg[:, 1:])) < 1e-12 + 1e-10 * np.abs(oagg[:, 1:]).max()
+    assert np.array_equal(hb.primal(x), agg) and np.array_equal(hb.jvp(y), dagg)
+    D = hb.dist_seq()
+    np.testing.assert_allclose(D.sum(axis=(0, 1)), 1.0, atol=1e-11)
