@@ -137,9 +137,11 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     el = (time.perf_counter() - t0) / reps
     tm = hb.last_timings()
     G8 = hb.G * 8
-    extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el,
-                           "k_fused_back_GBs": G8 * (1 + Nw) / (1e-3 * tm["dual_backward"]["ms"] / tm["dual_backward"]["launches"]) / 1e9,
-                           "k_fused_fwd_GBs": G8 * (1 + Nw) / (1e-3 * tm["dual_forward"]["ms"] / tm["dual_forward"]["launches"]) / 1e9}
+    np_ = tm["dual_backward"]["launches"] if hb.stats()["schedule"] == 1 else 1      # passes of the persistent schedule
+    per = (P * (np_ + Nw)) if hb.stats()["schedule"] == 1 else (tm["dual_backward"]["launches"] * (1 + Nw))
+    extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el, "passes": np_,
+                           "backward_sweep_GBs": G8 * per / (1e-3 * tm["dual_backward"]["ms"]) / 1e9,
+                           "forward_sweep_GBs": G8 * per / (1e-3 * tm["dual_forward"]["ms"]) / 1e9}
     # configs[1]'s grid with a mild shock and with RunMain.jl's Z_t = 1 + 0.8^t, then the headline grid
     for n_a, n_e, shock in ((500, 4, 0.01), (500, 4, 0.8), (2000, 11, 0.01)):
         try:
@@ -223,7 +225,8 @@ def main():
     hb.check()
     fence()
     t0 = time.perf_counter()
-    sweeps = {k: 0.0 for k in (("primal_backward", "primal_forward", "tangent_backward", "tangent_forward") if args.split
+    split_keys = args.split and hb.stats()["schedule"] == 0     # the persistent schedule runs a dual pass for every entry point
+    sweeps = {k: 0.0 for k in (("primal_backward", "primal_forward", "tangent_backward", "tangent_forward") if split_keys
                                else ("dual_backward", "dual_forward"))}
     for _ in range(args.steps):
         step()
@@ -245,6 +248,7 @@ def main():
         for k in acc:
             acc[k] += tmi[k]["ms"] / reps
     launches = {k: tm[k]["launches"] for k in tm}
+    schedule = hb.stats()["schedule"]
 
     if rank == 0:
         total_jvps = world * N * args.steps
@@ -252,10 +256,16 @@ def main():
         # dominant kernel: the per-period tangent kernels (k_tan_back / k_tan_fwd). One launch moves
         # the policy partials of ONE period for N directions: G*8*N algorithmic bytes
         # (B_alg = 2*P*G*8*(1+N) per batch = G*8 bytes per (sweep, period, direction)).
-        if args.split:
+        if split_keys:
             dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
             kname = {"tangent_backward": "k_tan_back", "tangent_forward": "k_tan_fwd"}[dom]
             bytes_per_launch = G * 8 * N
+        elif schedule == 1:
+            # XCD-local persistent sweeps: ONE launch carries a whole sweep (P periods) of the Float64 recurrence and the
+            # pass's directions: P*G*8*(1+N_pass) algorithmic bytes; a batch wider than 32 runs as ceil(N/32) passes
+            dom = max(("dual_backward", "dual_forward"), key=lambda k: acc[k])
+            kname = {"dual_backward": "k_xsweep_back", "dual_forward": "k_xsweep_fwd"}[dom]
+            bytes_per_launch = P * G * 8 * (launches[dom] + N) / launches[dom]
         else:   # a dual-sweep launch advances the primal and the N tangents by one period: G*8*(1+N)
             dom = max(("dual_backward", "dual_forward"), key=lambda k: acc[k])
             kname = {"dual_backward": "k_fused_back", "dual_forward": "k_fused_fwd"}[dom]
@@ -279,13 +289,14 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "grid": f"{n_a}x{n_e}", "T": T, "tangents_per_gpu": N,
-                       "step": ("1 primal sweep + 1 batched JVP of N tangents" if args.split else
+                       "step": ("1 primal sweep + 1 batched JVP of N tangents (hank_primal + hank_jvp)" if args.split else
                                 "1 dual-sweep pass: primal + N tangents (hank_primal_jvp)") + (" + RCCL all-gather" if use_dist else ""),
                        "parallelism": f"tangent-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": pmc,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_launch_s,
-                         "note": "avg launch = HIP-event time of the whole sweep / launches (includes the dependent-launch gaps)"},
+                         "schedule": "xcd-persistent" if schedule == 1 else "launch-per-period",
+                         "note": "avg launch = HIP-event time of the sweep's kernels on the library's stream / launches"},
             "whole_batch": {"B_alg_bytes": b_alg_batch, "achieved_GBs": b_alg_batch / (1e-3 * ms_per_step) / 1e9,
                             "frac_of_hbm_peak": b_alg_batch / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS},
             "sweeps_ms": {k: round(acc[k], 4) for k in acc}, "launches": launches,

@@ -46,7 +46,9 @@ enum {
     HANK_ERR_NOT_READY = 5,   /* boundary / primal not set before a dependent call                 */
     HANK_ERR_NONMONOTONE = 6, /* savings policy not monotone in wealth (cannot happen when the
                                  knots check passes; guards the segmented Young push-forward)      */
-    HANK_ERR_NOMEM = 7
+    HANK_ERR_NOMEM = 7,
+    HANK_ERR_SWEEP = 8        /* a persistent sweep could not form its workgroup groups or a wait in it timed out
+                                 (host-pointer entries fall back to the per-period launches by themselves)     */
 };
 
 /* value-function families resolved from the YAML `function:` name (KrusellSmith.yaml:86,
@@ -75,6 +77,7 @@ int hank_create(const hank_model *model, hank_ctx **out);
 int hank_destroy(hank_ctx *ctx);
 const char *hank_last_error(const hank_ctx *ctx); /* never NULL; "" when the last call succeeded  */
 int hank_n_hh(const hank_ctx *ctx);               /* household inputs per period (KS: 2)          */
+int hank_device_available(void);                  /* 1 when the current HIP device is a usable gfx950, else 0 */
 
 /* Use the caller's HIP stream (a hipStream_t) for everything this context enqueues; NULL restores
  * the context's own stream. */
@@ -143,6 +146,16 @@ int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dp
                            const double *D_prev, const double *dD_prev, int32_t N, double *D_out,
                            double *dD_out, double *agg_out, double *dagg_out);
 
+/* ---- steady state ---------------------------------------------------------
+ * hank_vfi == the inner fixed point of get_xVals (SteadyState.jl:132-141): value <- model.value_fn(value, xVals, model).Value
+ * until max|value_new - value| < tol — checked after EVERY step, like the reference — or max_iter steps (:134 caps at
+ * 10 000). The loop is device-resident: the EGM step kernels of hank_backward_step iterate on HBM, only a stop flag
+ * comes back per chunk of steps. value_io[G]: in = the starting value (ones in the reference, :132), out = the
+ * converged value; policy_out[G] = the policy of the step that produced it; *iters_out = steps taken,
+ * *supnorm_out = the last max|difference|. The price Newton and invariant_dist stay on the host. */
+int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t max_iter, double *value_io, double *policy_out,
+             int32_t *iters_out, double *supnorm_out);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * Device time, in milliseconds, of the sweeps of the most recent hank_primal[_dev]/hank_jvp[_dev],
  * from HIP events recorded on the context's stream around each sweep:
@@ -150,6 +163,13 @@ int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dp
  *   out[4] dual-sweep backward, out[5] dual-sweep forward (hank_primal_jvp); -1 where not applicable.
  * launches[k] = kernel launches inside sweep k. Valid after hank_sync. */
 int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]);
+
+/* Counters of this context (tests and scripts): out[0] sweep kernels launched by the persistent schedule, out[1] tangent
+ * workspaces allocated (a change of batch width N re-uses a cached workspace: a small most-recently-used cache, 3 deep),
+ * out[2] hipGraphs captured (per-period schedule), out[3] schedule in use (1 = XCD-local persistent sweeps, 0 = one
+ * launch per period), out[4] times this context fell back from 1 to 0, out[5] device-resident value-function iterations
+ * run by hank_vfi; the rest reserved. */
+int hank_stats(hank_ctx *ctx, int64_t out[8]);
 
 #ifdef __cplusplus
 }

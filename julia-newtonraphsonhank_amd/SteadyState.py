@@ -33,8 +33,16 @@ class SteadyState:
 class SSAssembler:
     """variable roles + padded-matrix assembly for the steady-state Newton solve (SteadyState.jl:55-93)."""
 
-    def __init__(self, model: SequenceModel, ss_spec, vfi_tol: float | None = None):
+    def __init__(self, model: SequenceModel, ss_spec, vfi_tol: float | None = None, vfi: str = "auto"):
+        """`vfi`: where the inner value-function fixed point runs — "device" (hank_vfi: the EGM step kernels of the hot
+        path iterated on the GPU), "host" (numpy), or "auto" = the device when an MI355X is present. Everything else of
+        the steady state (price Newton, lottery matrix, invariant_dist) is host work either way (north star)."""
         self.model, self.ss_spec = model, ss_spec
+        if vfi not in ("auto", "device", "host"):
+            raise ValueError(f"vfi must be 'auto', 'device' or 'host' (got {vfi!r})")
+        from .hip import device_available
+        self.vfi_on_device = vfi == "device" or (vfi == "auto" and device_available())
+        self.vfi_steps = 0
         self.all_keys = var_names(model)
         self.free_keys = tuple(k for k in vars_of_type(model, "endogenous") if k not in ss_spec.fixed)
         self.n_free = len(self.free_keys)
@@ -63,14 +71,26 @@ class SSAssembler:
             xv[k] = float(v)
         vf = model.value_fn
         value = self._value_warm if self._value_warm is not None else np.ones((self.endog_dim.n, self.n_exog))
-        res = vf.host_steady_state_step(value, xv, model)
-        for _ in range(10_000):
-            value_new = res["Value"]
-            tol = np.max(np.abs(value_new - value))
-            value = value_new
-            if tol < self.vfi_tol:
-                break
+        if self.vfi_on_device:
+            from .BackwardIteration import household_block
+            from .hip import KnotsNotSortedError
+            hb = household_block(model)
+            try:
+                v, pol, steps, _ = hb.vfi(value, [xv[k] for k in vf.household_inputs], self.vfi_tol, 10_000)
+            except KnotsNotSortedError as e:      # what the host step raises for find_ss's step halving
+                raise ValueError(str(e)) from e
+            self.vfi_steps += steps
+            res = {"Value": v, self.endog_dim.policy_var: pol}
+        else:
             res = vf.host_steady_state_step(value, xv, model)
+            for _ in range(10_000):
+                value_new = res["Value"]
+                tol = np.max(np.abs(value_new - value))
+                value = value_new
+                self.vfi_steps += 1
+                if tol < self.vfi_tol:
+                    break
+                res = vf.host_steady_state_step(value, xv, model)
         Λ_endog = make_endogenous_transition(res[self.endog_dim.policy_var], self.endog_dim, self.n_exog)
         D = invariant_dist((self.Λ_exog @ Λ_endog).T, D0=getattr(self, "_D_warm", None))
         self._D_warm = D
@@ -86,9 +106,9 @@ class SSAssembler:
         return np.tile(xVals[:, None], (1, T_pad))
 
 
-def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vfi_tol=None) -> SteadyState:
+def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vfi_tol=None, vfi: str = "auto") -> SteadyState:
     """Newton–Raphson on the free endogenous variables with step halving (SteadyState.jl:184-233)."""
-    asm = SSAssembler(model, ss_spec, vfi_tol)
+    asm = SSAssembler(model, ss_spec, vfi_tol, vfi)
 
     def F(p):
         return Residuals(asm(p), model)
@@ -134,7 +154,12 @@ def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vf
     xVals, ss_value, _ = asm.get_xVals(p)
     vars_ = {k: float(v) for k, v in zip(asm.all_keys, xVals)}
     # one more value-function call at the converged value for clean policies (:222-225)
-    res = model.value_fn.host_steady_state_step(ss_value, vars_, model)
+    if asm.vfi_on_device:
+        from .BackwardIteration import household_block
+        _, pol = household_block(model).backward_step(ss_value, [vars_[k] for k in model.value_fn.household_inputs])
+        res = {asm.endog_dim.policy_var: pol}
+    else:
+        res = model.value_fn.host_steady_state_step(ss_value, vars_, model)
     het_keys = vars_of_type(model, "heterogeneous")
     policies = {k: res[k] for k in het_keys}
     Λ_endog = make_endogenous_transition(policies[asm.endog_dim.policy_var], asm.endog_dim, asm.n_exog)
@@ -143,9 +168,9 @@ def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vf
     return SteadyState(vars_, policies, Λss, D, ss_value)
 
 
-def get_SteadyStates(model: SequenceModel, verbose: bool = False, vfi_tol=None):
+def get_SteadyStates(model: SequenceModel, verbose: bool = False, vfi_tol=None, vfi: str = "auto"):
     """both steady states (SteadyState.jl:245-259); one solve when the specs are the same object."""
-    ss_initial = find_ss(model, model.ss_initial, "initial", verbose, vfi_tol)
+    ss_initial = find_ss(model, model.ss_initial, "initial", verbose, vfi_tol, vfi)
     if model.ss_initial is model.ss_ending:
         return ss_initial, ss_initial
-    return ss_initial, find_ss(model, model.ss_ending, "ending", verbose, vfi_tol)
+    return ss_initial, find_ss(model, model.ss_ending, "ending", verbose, vfi_tol, vfi)

@@ -4,12 +4,15 @@
 // Y half of period t, so the loop-carried state only crosses a launch boundary once per period,
 // and the 2(T-1) dependent launches are replayed from hipGraphs (no host launch cost).
 #include "hank_kernels.h"
+#include "hank_xsweep.h"
 #include "../../include/hank_hip.h"
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <list>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -49,6 +52,31 @@ struct TanWork {
     bool valid = false;  // dpol holds the partials of the current primal
 };
 
+
+// ---- XCD-local persistent sweeps (hank_xsweep.h): per-context workspace and per-batch-width tangent buffers ----
+constexpr int XD_MAX = 4;           // directions per group and pass (D = 8 spills registers: wider batches run as passes)
+constexpr int XPASS_MAX = 64;       // passes per call: N <= 8 * XD_MAX * XPASS_MAX = 2048 directions
+struct XPass { int n0, N, D, groups; size_t dpol_off; };
+struct XTan {                       // one per batch width N (kept in a small LRU: Jacobian assembly and Newton alternate widths)
+    int N = 0;
+    std::vector<XPass> passes;
+    double *dxhh = nullptr, *dxr = nullptr, *dxw = nullptr, *dxt = nullptr;   // staging + [P][N] input tangents
+    double *dpol = nullptr;         // per pass [P][groups][G][D]
+    double *daggpart = nullptr;     // [P][Sact*n_e][XG*XD_MAX] (reused by every pass)
+    double *dagg_pass = nullptr;    // [P][XG*XD_MAX]
+    double *dagg_cm = nullptr;      // (P, N) column-major
+    bool valid = false;             // dpol holds the partials of the current primal
+};
+struct XWork {
+    bool ready = false;
+    int grid = 0, Sact = 0, maxt = 768, dmax = XD_MAX;
+    XSync *sync = nullptr;          // [2 * XPASS_MAX]: backward and forward sweep of every pass
+    double *st_s = nullptr, *st_ds = nullptr, *st_D = nullptr, *st_dD = nullptr;
+    double *Dvirt = nullptr, *aggpart = nullptr;
+    std::list<XTan> tans;           // most recently used first
+    int last_passes = 0;            // sync blocks the last call used (their status words are checked)
+};
+
 struct hank_ctx {
     int device = 0;
     Consts c{};
@@ -68,10 +96,15 @@ struct hank_ctx {
     hipEvent_t ev_fork = nullptr, ev_side = nullptr;
     bool side_pending = false;
     hipGraphExec_t g_pback = nullptr, g_pfwd = nullptr;
-    hipEvent_t ev[12] = {};
+    hipEvent_t ev[16] = {};
     bool ev_valid[6] = {false, false, false, false, false, false};
     int launches[6] = {0, 0, 0, 0, 0, 0};
     TanWork tw;
+    int schedule = 1;              // 1 = XCD-local persistent sweeps (default where supported), 0 = one launch per period
+    XWork xw;
+    XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
+    long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // see hank_stats
+    hipEvent_t ev_stream = nullptr;
     char errmsg[512] = {0};
 };
 
@@ -126,6 +159,7 @@ static int end_capture(hank_ctx *ctx, hipGraphExec_t *out) {
     HIPC(ctx, hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
     HIPC(ctx, hipGraphDestroy(graph));
     HIPC(ctx, hipGetLastError());
+    ctx->stats[2]++;
     return HANK_OK;
 }
 
@@ -139,7 +173,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     hipLaunchKernelGGL(k_egm_X, grd, blk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + c.n_hh * (P - 1),
-                       ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1);
+                       ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1, (const int *)nullptr);
     for (int t = P - 1; t >= 0; t--)
         hipLaunchKernelGGL(k_egm_step, grd, blk, lds, s, c, ctx->R, ctx->d_xhh, t, ctx->d_err);
     hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, P * c.n_e, ctx->d_err);
@@ -231,7 +265,7 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, c.n_hh, (int)P, N, w.dxr, w.dxw, w.dxt);
     hipLaunchKernelGGL(k_egm_X, pgrd, pblk, lds, s, c, ctx->d_ss_value, ctx->d_xhh + c.n_hh * (P - 1),
-                       ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, (int)P - 1);
+                       ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, (int)P - 1, (const int *)nullptr);
     cur = 0;
     for (int k = 0; k <= (int)P; k++) {
         const int tp = k < (int)P ? (int)P - 1 - k : -1;
@@ -268,7 +302,12 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
 static int ensure_tanwork(hank_ctx *ctx, int N) {
     TanWork &w = ctx->tw;
     if (w.N == N && w.g_back) return HANK_OK;
+    if (w.N) {      // the async entries may still have the old graphs in flight
+        HIPC(ctx, join_side(ctx));
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    }
     free_tanwork(w);
+    ctx->stats[1]++;
     const Consts &c = ctx->c;
     const size_t P = c.P, G = c.G;
     w.N = N;
@@ -308,12 +347,13 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     return VF == 2 ? capture_tangent_graphs<double, double2>(ctx, w, RGB, RGF, nbf) : capture_tangent_graphs<double, double>(ctx, w, RGB, RGF, nbf);
 }
 
+static int x_status(hank_ctx *ctx);
 static int fetch_device_error(hank_ctx *ctx) {
     int e[4] = {0, 0, 0, 0};
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e[0] == 0) return HANK_OK;
+    if (e[0] == 0) return ctx->schedule == 1 ? x_status(ctx) : HANK_OK;
     ctx->primal_done = false;
     switch (e[0]) {
     case ERR_KNOTS:
@@ -333,10 +373,221 @@ static int fetch_device_error(hank_ctx *ctx) {
     }
 }
 
+// ================================ XCD-local persistent sweeps: host side ==========================
+// Two persistent launches must never share the chip half-resident (each would wait for workgroups the other's
+// spinning workgroups keep out): every sweep launch of this process, from any context or stream, is ordered behind
+// the previous one through one event per device.
+static std::mutex g_xmutex;
+static hipEvent_t g_xlast[64] = {};
+
+static bool x_supported(const hank_ctx *ctx, int cus) {
+    const Consts &c = ctx->c;
+    const int Sact = (c.n_a + XRW - 1) / XRW;
+    return cus >= XG && Sact <= cus / XG && c.n_e <= 16;
+}
+
+static void x_free_tan(XTan &w) {
+    (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw); (void)hipFree(w.dxt);
+    (void)hipFree(w.dpol); (void)hipFree(w.daggpart); (void)hipFree(w.dagg_pass); (void)hipFree(w.dagg_cm);
+    w = XTan();
+}
+
+static void x_free(hank_ctx *ctx) {
+    XWork &X = ctx->xw;
+    for (XTan &w : X.tans) x_free_tan(w);
+    X.tans.clear();
+    ctx->xcur = nullptr;
+    (void)hipFree(X.sync); (void)hipFree(X.st_s); (void)hipFree(X.st_ds); (void)hipFree(X.st_D); (void)hipFree(X.st_dD);
+    (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart);
+    X = XWork();
+}
+
+static int x_setup(hank_ctx *ctx) {
+    XWork &X = ctx->xw;
+    if (X.ready) return HANK_OK;
+    const Consts &c = ctx->c;
+    hipDeviceProp_t prop;
+    HIPC(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    X.grid = (prop.multiProcessorCount / XG) * XG;
+    X.Sact = (c.n_a + XRW - 1) / XRW;
+    X.maxt = c.n_e <= 12 ? 768 : 1024;      // 64*n_e threads per workgroup; the register budget follows the bound
+    X.dmax = c.n_e <= 12 ? XD_MAX : 2;
+    const size_t G = c.G, GV = G + 64 * (size_t)c.n_e, P = c.P;
+    HIPC(ctx, dmalloc(&X.sync, (size_t)2 * XPASS_MAX));
+    HIPC(ctx, dmalloc(&X.st_s, 2 * XG * G));
+    HIPC(ctx, dmalloc(&X.st_ds, 2 * XG * G * X.dmax));
+    HIPC(ctx, dmalloc(&X.st_D, 2 * XG * GV));
+    HIPC(ctx, dmalloc(&X.st_dD, 2 * XG * GV * X.dmax));
+    HIPC(ctx, dmalloc(&X.Dvirt, P * c.n_e * 64));
+    HIPC(ctx, dmalloc(&X.aggpart, P * (size_t)X.Sact * c.n_e));
+    HIPC(ctx, hipMemset(X.Dvirt, 0, sizeof(double) * P * c.n_e * 64));
+    X.ready = true;
+    return HANK_OK;
+}
+
+// tangent buffers for a batch of N directions, from a small most-recently-used cache (Jacobian assembly at N = 256
+// and the Newton inner loop at N = 1 alternate: neither re-allocates)
+static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
+    XWork &X = ctx->xw;
+    for (auto it = X.tans.begin(); it != X.tans.end(); ++it)
+        if (it->N == N) { X.tans.splice(X.tans.begin(), X.tans, it); *out = &X.tans.front(); return HANK_OK; }
+    if (N > 8 * X.dmax * XPASS_MAX) return fail(ctx, HANK_ERR_BAD_ARG, "N=%d exceeds %d directions per call", N, 8 * X.dmax * XPASS_MAX);
+    const char *ce = getenv("HANK_TAN_CACHE");
+    const size_t keep = ce ? (size_t)atoi(ce) : 3;
+    while (X.tans.size() >= (keep ? keep : 1)) {       // evict the least recently used — after the stream has drained
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->xcur == &X.tans.back()) ctx->xcur = nullptr;
+        x_free_tan(X.tans.back());
+        X.tans.pop_back();
+    }
+    X.tans.emplace_front();
+    XTan &w = X.tans.front();
+    const Consts &c = ctx->c;
+    const size_t P = c.P, G = c.G;
+    w.N = N;
+    size_t off = 0;
+    for (int n0 = 0; n0 < N; n0 += XG * X.dmax) {
+        XPass ps;
+        ps.n0 = n0; ps.N = std::min(N - n0, XG * X.dmax);
+        ps.D = 1; while (XG * ps.D < ps.N) ps.D *= 2;
+        ps.groups = (ps.N + ps.D - 1) / ps.D;
+        ps.dpol_off = off;
+        off += P * ps.groups * G * ps.D;
+        w.passes.push_back(ps);
+    }
+    ctx->stats[1]++;
+    HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
+    HIPC(ctx, dmalloc(&w.dxr, P * N)); HIPC(ctx, dmalloc(&w.dxw, P * N)); HIPC(ctx, dmalloc(&w.dxt, P * N));
+    HIPC(ctx, dmalloc(&w.dpol, off));
+    const size_t W = (size_t)XG * X.dmax;
+    HIPC(ctx, dmalloc(&w.daggpart, P * X.Sact * c.n_e * W));
+    HIPC(ctx, hipMemset(w.daggpart, 0, sizeof(double) * P * X.Sact * c.n_e * W));
+    HIPC(ctx, dmalloc(&w.dagg_pass, P * W));
+    HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
+    *out = &w;
+    return HANK_OK;
+}
+
+template <int MAXT>
+static void x_launch(int D, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XBackArgs &ab, const XFwdArgs &af) {
+#define XL(DV)                                                                                       \
+    do {                                                                                             \
+        if (back) hipLaunchKernelGGL((k_xsweep_back<DV, MAXT>), grd, blk, lds, s, ab);               \
+        else hipLaunchKernelGGL((k_xsweep_fwd<DV, MAXT>), grd, blk, lds, s, af);                     \
+    } while (0)
+    if (D == 0) XL(0);
+    else if (D == 1) XL(1);
+    else if (D == 2) XL(2);
+    else if (D == 4) { if constexpr (MAXT == 768) XL(4); }
+#undef XL
+}
+
+// the whole household block at the context's current x (d_xhh) and boundary: Float64 recurrences (w == nullptr) or
+// value and the N partials of `w` together — two persistent launches per pass (backward, forward)
+static int x_run(hank_ctx *ctx, XTan *w) {
+    XWork &X = ctx->xw;
+    const Consts &c = ctx->c;
+    const size_t P = c.P, G = c.G;
+    hipStream_t s = ctx->stream;
+    {
+        std::lock_guard<std::mutex> lk(g_xmutex);
+        if (g_xlast[ctx->device & 63]) HIPC(ctx, hipStreamWaitEvent(s, g_xlast[ctx->device & 63], 0));
+    }
+    static const std::vector<XPass> primal_only{XPass{0, 0, 0, 1, 0}};
+    const std::vector<XPass> &passes = w ? w->passes : primal_only;
+    const int np = (int)passes.size();
+    HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync) * 2 * np, s));
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
+    const int N = w ? w->N : 0;
+    if (w) hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
+    const dim3 grd(X.grid), blk(64 * c.n_e);
+    XBackArgs ab{};
+    ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.Ntot = N > 0 ? N : 1;
+    ab.st_s = X.st_s; ab.st_ds = X.st_ds; ab.pol = ctx->R.pol; ab.err = ctx->d_err;
+    XFwdArgs af{};
+    af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.st_D = X.st_D; af.st_dD = X.st_dD;
+    af.Dseq = ctx->R.Dseq; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart;
+    HIPC(ctx, hipEventRecord(ctx->ev[8], s));
+    for (int p = 0; p < np; p++) {
+        const XPass &ps = passes[p];
+        ab.dxr = w ? w->dxr : nullptr; ab.dxw = w ? w->dxw : nullptr; ab.dxt = w ? w->dxt : nullptr;
+        ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 * p;
+        ab.dpol = w ? w->dpol + ps.dpol_off : nullptr;
+        const size_t lds = sizeof(double) * ((size_t)(1 + ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e) + 64;
+        if (X.maxt == 768) x_launch<768>(ps.D, true, grd, blk, lds, s, ab, af);
+        else x_launch<1024>(ps.D, true, grd, blk, lds, s, ab, af);
+        ctx->stats[0]++;
+    }
+    HIPC(ctx, hipEventRecord(ctx->ev[9], s));
+    hipLaunchKernelGGL(k_lottery, dim3((unsigned)(P * c.n_e)), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
+    const int nb = X.Sact * c.n_e;
+    HIPC(ctx, hipEventRecord(ctx->ev[11], s));
+    for (int p = 0; p < np; p++) {
+        const XPass &ps = passes[p];
+        af.sy = X.sync + 2 * p + 1; af.groups = ps.groups; af.N = ps.N;
+        af.dpol = w ? w->dpol + ps.dpol_off : nullptr; af.daggpart = w ? w->daggpart : nullptr;
+        const size_t lds = sizeof(double) * ((size_t)(1 + ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e) + 64;
+        if (X.maxt == 768) x_launch<768>(ps.D, false, grd, blk, lds, s, ab, af);
+        else x_launch<1024>(ps.D, false, grd, blk, lds, s, ab, af);
+        ctx->stats[0]++;
+        if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[12], s));
+        if (w) {
+            const int W = XG * ps.D;
+            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, W, w->dagg_pass);
+            hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, W, ps.n0, ps.N, w->dagg_cm);
+        }
+    }
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, nb, 1, ctx->d_agg);
+    hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
+    HIPC(ctx, hipEventRecord(ctx->ev[10], s));
+    HIPC(ctx, hipGetLastError());
+    {
+        std::lock_guard<std::mutex> lk(g_xmutex);
+        hipEvent_t &e = g_xlast[ctx->device & 63];
+        if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPC(ctx, hipEventRecord(e, s));
+    }
+    X.last_passes = np;
+    ctx->launches[4] = ctx->launches[5] = np;
+    ctx->ev_valid[4] = ctx->ev_valid[5] = true;
+    ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
+    ctx->primal_done = true;
+    for (XTan &t : X.tans) t.valid = false;
+    if (w) w->valid = true;
+    ctx->xcur = w;
+    (void)G;
+    return HANK_OK;
+}
+
+// after a synchronisation: did every sweep of the last call form its groups and meet all its barriers?
+static int x_status(hank_ctx *ctx) {
+    XWork &X = ctx->xw;
+    if (!X.ready || X.last_passes == 0) return HANK_OK;
+    std::vector<XSync> h(2 * (size_t)X.last_passes);
+    HIPC(ctx, hipMemcpy(h.data(), X.sync, sizeof(XSync) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < h.size(); k++)
+        if (h[k].status[0] != 0) {
+            ctx->primal_done = false;
+            for (XTan &t : X.tans) t.valid = false;
+            return fail(ctx, HANK_ERR_SWEEP, "persistent %s sweep of pass %zu: %s on XCD %u (workgroups per XCD: %u %u %u %u %u %u %u %u)",
+                        (k & 1) ? "forward" : "backward", k / 2, h[k].status[0] == XERR_PLACEMENT ? "a group is short of members" : "a wait timed out",
+                        h[k].status[1], h[k].ticket[0][0], h[k].ticket[1][0], h[k].ticket[2][0], h[k].ticket[3][0], h[k].ticket[4][0],
+                        h[k].ticket[5][0], h[k].ticket[6][0], h[k].ticket[7][0]);
+        }
+    return HANK_OK;
+}
+
 // ================================ C ABI =========================================================
 extern "C" {
 
 const char *hank_last_error(const hank_ctx *ctx) { return ctx ? ctx->errmsg : "null context"; }
+int hank_device_available(void) {
+    int ndev = 0, dev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
 int hank_n_hh(const hank_ctx *ctx) { return ctx ? ctx->c.n_hh : 0; }
 
 int hank_create(const hank_model *m, hank_ctx **out) {
@@ -371,7 +622,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPC(ctx, hipEventCreate(&ctx->ev_side));
-    for (int k = 0; k < 12; k++) HIPC(ctx, hipEventCreate(&ctx->ev[k]));
+    for (int k = 0; k < 16; k++) HIPC(ctx, hipEventCreate(&ctx->ev[k]));
     HIPC(ctx, dmalloc(&ctx->d_a, c.n_a));
     HIPC(ctx, dmalloc(&ctx->d_z, c.n_e));
     HIPC(ctx, dmalloc(&ctx->d_Pi, (size_t)c.n_e * c.n_e));
@@ -397,7 +648,18 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, dmalloc(&ctx->d_aggpart, P * (size_t)ctx->nbp));
     HIPC(ctx, dmalloc(&ctx->d_err, 4));
     HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
-    int rc = build_primal_graphs(ctx);
+    HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_stream, hipEventDisableTiming));
+    // schedule: XCD-local persistent sweeps wherever the grid fits one workgroup row-slab per CU of an XCD; the
+    // per-period launches otherwise (and as the fall-back when a sweep cannot form its groups). HANK_SCHEDULE=launch|xcd
+    // forces one (dev knob / A-B).
+    const char *se = getenv("HANK_SCHEDULE");
+    ctx->schedule = x_supported(ctx, prop.multiProcessorCount) ? 1 : 0;
+    if (se && strcmp(se, "launch") == 0) ctx->schedule = 0;
+    if (se && strcmp(se, "xcd") == 0 && ctx->schedule == 0)
+        return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=xcd: n_a=%d needs %d workgroups per XCD, the device has %d", c.n_a, (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG);
+    int rc = HANK_OK;
+    if (ctx->schedule == 0) rc = build_primal_graphs(ctx);
+    else rc = x_setup(ctx);
     if (rc) return rc;
     ctx->errmsg[0] = 0;
     return HANK_OK;
@@ -408,6 +670,8 @@ int hank_destroy(hank_ctx *ctx) {
     if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     free_tanwork(ctx->tw);
+    x_free(ctx);
+    if (ctx->ev_stream) (void)hipEventDestroy(ctx->ev_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -418,7 +682,7 @@ int hank_destroy(hank_ctx *ctx) {
     (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo); (void)hipFree(R.lwg); (void)hipFree(R.seg);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
     (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
-    for (int k = 0; k < 12; k++)
+    for (int k = 0; k < 16; k++)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -427,7 +691,13 @@ int hank_destroy(hank_ctx *ctx) {
 
 int hank_set_stream(hank_ctx *ctx, void *hip_stream) {
     if (!ctx) return HANK_ERR_BAD_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next != ctx->stream) {      // what is still queued on the old stream (and on the side stream) happens before the new one's work
+        HIPC(ctx, join_side(ctx));
+        HIPC(ctx, hipEventRecord(ctx->ev_stream, ctx->stream));
+        HIPC(ctx, hipStreamWaitEvent(next, ctx->ev_stream, 0));
+    }
+    ctx->stream = next;
     return HANK_OK;
 }
 
@@ -475,9 +745,50 @@ static int run_primal(hank_ctx *ctx, double *d_agg_out) {
     return HANK_OK;
 }
 
+// ---- xcd schedule: entry-point bodies --------------------------------------------------------------
+static int x_primal(hank_ctx *ctx, const double *xhh, hipMemcpyKind kind, double *d_agg_out) {
+    int rc = x_setup(ctx);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * ctx->c.P, kind, ctx->stream));
+    rc = x_run(ctx, nullptr);
+    if (rc) return rc;
+    if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * ctx->c.P, hipMemcpyDeviceToDevice, ctx->stream));
+    return HANK_OK;
+}
+// value and N partials in one dual pass; xhh == nullptr keeps the context's current x (hank_jvp: the Dual pass
+// recomputes the Float64 recurrence from the same inputs, bit for bit, like NewtonRaphson.jl:95 does)
+static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcpyKind kind, int N, double *d_agg_out, double *d_dagg_out) {
+    int rc = x_setup(ctx);
+    if (rc) return rc;
+    XTan *w = nullptr;
+    rc = x_ensure_tan(ctx, N, &w);
+    if (rc) return rc;
+    const size_t P = ctx->c.P;
+    if (xhh) HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, kind, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
+    rc = x_run(ctx, w);
+    if (rc) return rc;
+    if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, w->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    return HANK_OK;
+}
+// a sweep could not form its groups (or timed out): this context continues on the per-period launches
+static int to_launch_schedule(hank_ctx *ctx) {
+    ctx->schedule = 0;
+    ctx->stats[4]++;
+    ctx->primal_done = false;
+    if (!ctx->g_pback) return build_primal_graphs(ctx);
+    return HANK_OK;
+}
+static bool x_fallback_allowed() {
+    const char *se = getenv("HANK_SCHEDULE");
+    return !(se && strcmp(se, "xcd") == 0);      // a forced schedule fails loudly instead
+}
+
 int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
     if (!ctx || !d_xhh) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    if (ctx->schedule == 1) return x_primal(ctx, d_xhh, hipMemcpyDeviceToDevice, d_agg_out);
     const size_t P = ctx->c.P;
     HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyDeviceToDevice, ctx->stream));
     return run_primal(ctx, d_agg_out);
@@ -494,11 +805,22 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
     const size_t P = ctx->c.P;
     for (size_t t = 0; t < P; t++)
         if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
-    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyHostToDevice, ctx->stream));
-    int rc = run_primal(ctx, nullptr);
-    if (rc) return rc;
-    rc = fetch_device_error(ctx);
-    if (rc) return rc;
+    int rc = HANK_OK;
+    if (ctx->schedule == 1) {
+        rc = x_primal(ctx, xhh, hipMemcpyHostToDevice, nullptr);
+        if (rc) return rc;
+        rc = fetch_device_error(ctx);
+        if (rc == HANK_ERR_SWEEP && x_fallback_allowed()) rc = to_launch_schedule(ctx);
+        else if (rc) return rc;
+        if (rc) return rc;
+    }
+    if (ctx->schedule == 0) {
+        HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyHostToDevice, ctx->stream));
+        rc = run_primal(ctx, nullptr);
+        if (rc) return rc;
+        rc = fetch_device_error(ctx);
+        if (rc) return rc;
+    }
     if (agg_out) {
         HIPC(ctx, hipMemcpyAsync(agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
         HIPC(ctx, hipStreamSynchronize(ctx->stream));
@@ -524,6 +846,7 @@ static int run_jvp(hank_ctx *ctx) {
 int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_out) {
     if (!ctx || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
+    if (ctx->schedule == 1) return x_dual(ctx, nullptr, d_dxhh, hipMemcpyDeviceToDevice, N, nullptr, d_dagg_out);
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
     const size_t P = ctx->c.P;
@@ -537,9 +860,29 @@ int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_
 int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
     if (!ctx || !dxhh || !dagg_out || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
-    int rc = ensure_tanwork(ctx, N);
-    if (rc) return rc;
     const size_t P = ctx->c.P;
+    int rc = HANK_OK;
+    if (ctx->schedule == 1) {
+        rc = x_dual(ctx, nullptr, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
+        if (rc) return rc;
+        rc = fetch_device_error(ctx);
+        if (rc == HANK_ERR_SWEEP && x_fallback_allowed()) {
+            rc = to_launch_schedule(ctx);
+            if (rc) return rc;
+            rc = run_primal(ctx, nullptr);       // the launch schedule needs its own record of the primal at the current x
+            if (rc) return rc;
+            rc = fetch_device_error(ctx);
+        }
+        if (rc) return rc;
+        if (ctx->schedule == 1) {
+            HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->xcur->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+            HIPC(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->errmsg[0] = 0;
+            return HANK_OK;
+        }
+    }
+    rc = ensure_tanwork(ctx, N);
+    if (rc) return rc;
     HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
     rc = run_jvp(ctx);
     if (rc) return rc;
@@ -568,6 +911,7 @@ int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh
                         double *d_dagg_out) {
     if (!ctx || !d_xhh || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    if (ctx->schedule == 1) return x_dual(ctx, d_xhh, d_dxhh, hipMemcpyDeviceToDevice, N, d_agg_out, d_dagg_out);
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
     const size_t P = ctx->c.P;
@@ -587,19 +931,40 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
     const size_t P = ctx->c.P;
     for (size_t t = 0; t < P; t++)
         if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
-    int rc = ensure_tanwork(ctx, N);
-    if (rc) return rc;
-    HIPC(ctx, join_side(ctx));
-    HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyHostToDevice, ctx->stream));
-    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
-    rc = run_fused(ctx);
-    if (rc) return rc;
-    rc = fetch_device_error(ctx);
-    if (rc) { ctx->tw.valid = false; return rc; }
+    int rc = HANK_OK;
+    const double *d_dagg = nullptr;
+    if (ctx->schedule == 1) {
+        rc = x_dual(ctx, xhh, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
+        if (rc) return rc;
+        rc = fetch_device_error(ctx);
+        if (rc == HANK_ERR_SWEEP && x_fallback_allowed()) rc = to_launch_schedule(ctx);
+        else if (rc) return rc;
+        if (rc) return rc;
+        if (ctx->schedule == 1) d_dagg = ctx->xcur->dagg_cm;
+    }
+    if (ctx->schedule == 0) {
+        rc = ensure_tanwork(ctx, N);
+        if (rc) return rc;
+        HIPC(ctx, join_side(ctx));
+        HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
+        rc = run_fused(ctx);
+        if (rc) return rc;
+        rc = fetch_device_error(ctx);
+        if (rc) { ctx->tw.valid = false; return rc; }
+        d_dagg = ctx->tw.dagg_cm;
+    }
     if (agg_out) HIPC(ctx, hipMemcpyAsync(agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(dagg_out, d_dagg, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+int hank_stats(hank_ctx *ctx, int64_t out[8]) {
+    if (!ctx || !out) return HANK_ERR_BAD_ARG;
+    ctx->stats[3] = ctx->schedule;
+    for (int k = 0; k < 8; k++) out[k] = ctx->stats[k];
     return HANK_OK;
 }
 
@@ -607,7 +972,8 @@ int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]) {
     if (!ctx || !out_ms) return HANK_ERR_BAD_ARG;
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    const int a[6] = {0, 6, 3, 7, 8, 9}, b[6] = {1, 2, 4, 5, 9, 10};
+    int a[6] = {0, 6, 3, 7, 8, 9}, b[6] = {1, 2, 4, 5, 9, 10};
+    if (ctx->schedule == 1) { a[5] = 11; b[5] = 12; }      // the forward sweep kernels alone (lottery and reductions excluded)
     for (int k = 0; k < 6; k++) {
         out_ms[k] = -1.0;
         if (ctx->ev_valid[k]) {
@@ -640,10 +1006,26 @@ int hank_get_dist_seq(hank_ctx *ctx, double *out) {
 
 int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
-    TanWork &w = ctx->tw;
-    if (!w.valid || w.N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
     const size_t total = (size_t)ctx->c.P * ctx->c.G * N;
     double *tmp = nullptr;
+    if (ctx->schedule == 1) {
+        XTan *x = ctx->xcur;
+        if (!x || !x->valid || x->N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
+        HIPC(ctx, dmalloc(&tmp, total));
+        for (const XPass &ps : x->passes) {
+            const size_t cnt = (size_t)ctx->c.P * ctx->c.G * ps.N;
+            hipLaunchKernelGGL(k_xexport_dpol, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, x->dpol + ps.dpol_off, ctx->c.G, ctx->c.P,
+                               ps.groups, ps.D, ps.n0, ps.N, tmp);
+        }
+        hipError_t e1 = hipMemcpyAsync(out, tmp, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+        HIPC(ctx, e1);
+        HIPC(ctx, e2);
+        return HANK_OK;
+    }
+    TanWork &w = ctx->tw;
+    if (!w.valid || w.N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
     HIPC(ctx, dmalloc(&tmp, total));
     hipLaunchKernelGGL(k_export_dpol, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w.dpol, ctx->c.G, ctx->c.P, N, tmp);
     hipError_t e1 = hipMemcpyAsync(out, tmp, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream);
@@ -686,8 +1068,8 @@ static int granular_backward(hank_ctx *ctx, const double *value_next, const doub
     HIPC(ctx, hipMemcpyAsync(xt, xhh_t, sizeof(double) * c.n_hh, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
-    hipLaunchKernelGGL(k_egm_X, grd, blk, primal_lds(c), s, c, Vin, xt, sK, kc, ctx->d_err, 0);
-    hipLaunchKernelGGL(k_egm_Y, grd, blk, 0, s, c, sK, xhh_t[0], xhh_t[1], c.n_hh > 2 ? xhh_t[2] : 0.0, pol, ib, A, B, u, v, Vout, ctx->d_err, 0);
+    hipLaunchKernelGGL(k_egm_X, grd, blk, primal_lds(c), s, c, Vin, xt, sK, kc, ctx->d_err, 0, (const int *)nullptr);
+    hipLaunchKernelGGL(k_egm_Y, grd, blk, 0, s, c, sK, xhh_t[0], xhh_t[1], c.n_hh > 2 ? xhh_t[2] : 0.0, pol, ib, A, B, u, v, Vout, ctx->d_err, 0, (const int *)nullptr);
     HIPC(ctx, hipGetLastError());
     const bool was_done = ctx->primal_done;
     int rc = fetch_device_error(ctx);
@@ -731,6 +1113,64 @@ int hank_backward_step_dual(hank_ctx *ctx, const double *value_next, const doubl
     return granular_backward(ctx, value_next, dvalue_next, xhh_t, dxhh_t, N, value_out, dvalue_out, policy_out, dpolicy_out);
 }
 }  // extern "C"
+
+// ---- steady state: the inner fixed point of get_xVals on the device (SteadyState.jl:132-141) ------------------
+extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t max_iter, double *value_io, double *policy_out,
+                        int32_t *iters_out, double *supnorm_out) {
+    if (!ctx || !xhh_t || !value_io || !policy_out || max_iter < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument");
+    if (!(1.0 + xhh_t[0] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive");
+    const Consts &c = ctx->c;
+    const size_t G = c.G;
+    hipStream_t s = ctx->stream;
+    Scratch sc;
+    double *V[2], *xt, *sK, *kc, *A, *B, *u, *v, *pol, *norm;
+    int *ib, *state;
+    HIPC(ctx, sc.alloc(&V[0], G)); HIPC(ctx, sc.alloc(&V[1], G)); HIPC(ctx, sc.alloc(&xt, 4)); HIPC(ctx, sc.alloc(&sK, G));
+    HIPC(ctx, sc.alloc(&kc, G)); HIPC(ctx, sc.alloc(&A, G)); HIPC(ctx, sc.alloc(&B, G)); HIPC(ctx, sc.alloc(&u, G));
+    HIPC(ctx, sc.alloc(&v, G)); HIPC(ctx, sc.alloc(&pol, G)); HIPC(ctx, sc.alloc(&norm, 1)); HIPC(ctx, sc.alloc(&ib, G));
+    HIPC(ctx, sc.alloc(&state, 2));
+    HIPC(ctx, join_side(ctx));
+    HIPC(ctx, hipMemcpyAsync(V[0], value_io, sizeof(double) * G, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemcpyAsync(xt, xhh_t, sizeof(double) * c.n_hh, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemsetAsync(state, 0, 2 * sizeof(int), s));
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
+    const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
+    const double r = xhh_t[0], w = xhh_t[1], tr = c.n_hh > 2 ? xhh_t[2] : 0.0;
+    int hstate[2] = {0, 0};
+    int done = 0;                      // steps enqueued
+    const int chunk = 64;              // the stop flag travels to the host once per chunk; converged steps freeze the state
+    while (!hstate[0] && done < max_iter) {
+        const int n = std::min(chunk, max_iter - done);
+        for (int k = 0; k < n; k++) {
+            const int cur = (done + k) & 1;
+            hipLaunchKernelGGL(k_egm_X, grd, blk, primal_lds(c), s, c, V[cur], xt, sK, kc, ctx->d_err, 0, (const int *)state);
+            hipLaunchKernelGGL(k_egm_Y, grd, blk, 0, s, c, sK, r, w, tr, pol, ib, A, B, u, v, V[cur ^ 1], ctx->d_err, 0, (const int *)state);
+            hipLaunchKernelGGL(k_vfi_check, dim3(1), dim3(1024), 0, s, V[cur ^ 1], V[cur], (int)G, tol, state, norm);
+        }
+        done += n;
+        HIPC(ctx, hipGetLastError());
+        HIPC(ctx, hipMemcpyAsync(hstate, state, sizeof(hstate), hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipStreamSynchronize(s));
+        int e[4];
+        HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
+        if (e[0] == ERR_KNOTS)
+            return fail(ctx, HANK_ERR_KNOTS, "knot-vectors must be unique and sorted in increasing order (steady-state value iteration, step %d, "
+                        "productivity state %d, wealth index %d)", hstate[1] + 1, e[2] + 1, e[3] + 1);
+        if (e[0] == ERR_DOMAIN)
+            return fail(ctx, HANK_ERR_DOMAIN, "DomainError: negative base under a non-integer power (steady-state value iteration, step %d)", hstate[1] + 1);
+    }
+    const int fin = hstate[1] & 1;     // step k reads V[(k-1)&1] and writes V[k&1]
+    double hn = 0.0;
+    HIPC(ctx, hipMemcpyAsync(value_io, V[fin], sizeof(double) * G, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipMemcpyAsync(policy_out, pol, sizeof(double) * G, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipMemcpyAsync(&hn, norm, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipStreamSynchronize(s));
+    if (iters_out) *iters_out = hstate[1];
+    if (supnorm_out) *supnorm_out = hn;
+    ctx->stats[5] += hstate[1];
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
 
 static int granular_forward(hank_ctx *ctx, const double *policy, const double *dpolicy, const double *D_prev,
                             const double *dD_prev, int N, double *D_out, double *dD_out, double *agg_out, double *dagg_out) {

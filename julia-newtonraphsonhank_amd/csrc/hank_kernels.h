@@ -160,7 +160,10 @@ struct YOut {
 };
 // `guess` (>= 0): the bracket of the same point one period later — brackets move by a few knots per
 // period, so a probe there plus a short gallop replaces the 11 dependent loads of a cold bisection.
-__device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, double r, double w, double tr,
+// `sc` is anything indexable that returns the knot s_t[i, e] (a plain pointer; the XCD-local sweep passes a
+// loader that reads the L2-resident state with L1-bypassing loads) — the arithmetic is the same for both.
+template <typename KNOTS>
+__device__ inline YOut egm_Y(const Consts &c, const KNOTS sc, int a, int e, double r, double w, double tr,
                              int *err, int t, int guess) {
     YOut o;
     const int n = c.n_a;
@@ -239,9 +242,11 @@ __device__ inline YOut egm_Y(const Consts &c, const double *sc, int a, int e, do
 
 // block = RBP rows x n_e columns; thread (row, e) with row fastest. dynamic LDS:
 // Vsh[n_e*RBP] + Pish[n_e*n_e]
+// `stop` (may be null): the device-resident value-function iteration freezes its state once it has converged
 __global__ void k_egm_X(Consts c, const double *Vin, const double *xt, double *s_out,
-                        double *kc_out, int *err, int t) {
+                        double *kc_out, int *err, int t, const int *stop) {
     extern __shared__ double sh[];
+    if (stop && *stop) return;
     double *Vsh = sh, *Pish = sh + c.n_e * RBP;
     const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
     const int a = blockIdx.x * RBP + row;
@@ -253,7 +258,8 @@ __global__ void k_egm_X(Consts c, const double *Vin, const double *xt, double *s
 
 // Y only (granular step): record slot pointers are for ONE period
 __global__ void k_egm_Y(Consts c, const double *s, double r, double w, double tr, double *pol, int *ib,
-                        double *A, double *B, double *u, double *v, double *Vout, int *err, int t) {
+                        double *A, double *B, double *u, double *v, double *Vout, int *err, int t, const int *stop) {
+    if (stop && *stop) return;
     const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
     const int a = blockIdx.x * RBP + row;
     if (a >= c.n_a) return;
@@ -400,6 +406,31 @@ __device__ inline void dist_step_body(const Consts &c, const Record &R, int t, d
 __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
     extern __shared__ double sh[];
     dist_step_body(c, R, t, aggpart, blockIdx.x, gridDim.x, sh);
+}
+
+// one convergence check of the steady state's inner fixed point (SteadyState.jl:136-139: max|value_new - value| < tol,
+// after EVERY step): one block; state = {stop, steps done}. A NaN norm never stops the loop, as in the reference.
+__global__ void k_vfi_check(const double *Vnew, const double *Vold, int G, double tol, int *state, double *norm_out) {
+    __shared__ double red[16];
+    if (state[0]) return;
+    double m = 0.0;
+    bool bad = false;
+    for (int i = threadIdx.x; i < G; i += blockDim.x) {
+        const double d = fabs(Vnew[i] - Vold[i]);
+        if (!(d == d)) bad = true;
+        m = d > m ? d : m;
+    }
+    if (bad) m = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(m, off, 64); m = (o > m || !(o == o)) ? o : m; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); k++) m = (red[k] > m || !(red[k] == red[k])) ? red[k] : m;
+        state[1] += 1;
+        *norm_out = m;
+        if (m < tol) state[0] = 1;
+    }
 }
 
 // zero fills as kernels (no memset nodes inside the captured graphs)

@@ -1,0 +1,514 @@
+// hank_xsweep.h — the XCD-local persistent DUAL sweeps: ONE launch per sweep instead of one per period.
+//
+// What the reference does under Dual{Tag,Float64,N} (NewtonRaphson.jl:95: value and partials travel together through
+// BackwardIteration.jl:90-113 and ForwardIteration.jl:297-308) is done here literally: every workgroup carries the
+// Float64 recurrence AND D partials for its grid points, period after period, inside one kernel.
+//
+// Mapping (MI355X: 8 XCDs x 32 CUs, one 4 MiB L2 per XCD, L2s not coherent with each other):
+//   * a launch has one workgroup per CU; each workgroup reads the XCD it actually runs on (HW_REG_XCC_ID) and takes a
+//     ticket there: the workgroups of one XCD form a GROUP. Nothing assumes a placement — a group that does not have
+//     the members it needs reports XERR_PLACEMENT and the host falls back to the per-period launches.
+//   * group x owns the tangent directions [x*D, (x+1)*D) of the batch (D = 1, 2, 4 or 8); the Float64 recurrence is
+//     computed redundantly by every group (it is 1/(1+D) of the arithmetic and none of the HBM traffic).
+//   * inside a group, workgroup c owns 63 wealth rows (all n_e productivity columns: wave = column, lane = row).
+//   * the loop-carried state (EGM knots s_t and their partials ds_t backward; D_t and dD_t forward) lives in a small
+//     ping-pong buffer that never leaves the XCD's L2: written with plain stores, read back — after ONE group barrier
+//     per period — with sc1 loads, which bypass the reading CU's L1 and are served by that same L2. No kernel boundary,
+//     no cross-XCD traffic, no fence: the only HBM streams are the algorithmic ones (the policy-partials sequence,
+//     written once backward and read once forward) plus the policy / lottery records.
+//   * group barrier = every wave drains its stores (vmcnt(0)), workgroup barrier, one lane adds to the group's counter
+//     and polls it. Every spin is bounded; on timeout a status word is set and every later wait falls through, so the
+//     grid always drains.
+//
+// Layouts:  state  st_s [2][XG][G], st_ds [2][XG][G][D]                       (backward)
+//                  st_D [2][XG][G+64*n_e], st_dD [2][XG][G+64*n_e][D]         (forward; the tail holds the virtual rows)
+//           dpol   [P][groups][n_e][n_a][D]   — a group's stream is contiguous: whole lines, one XCD each.
+#pragma once
+#include "hank_kernels.h"
+
+namespace hank {
+
+constexpr int XG = 8;             // groups = XCDs
+constexpr int XRW = 63;           // wealth rows per workgroup; lane 63 of every wave is the forward sweep's virtual row
+constexpr unsigned XSPIN_LIMIT = 1u << 21;
+enum { XERR_TIMEOUT = 1, XERR_PLACEMENT = 2 };
+
+struct XSync {                    // zeroed by a memset node before EVERY launch (2560 B, a multiple of 16)
+    unsigned ticket[XG][32];      // [x][0]: workgroups that arrived on XCD x (one 128-B line each)
+    unsigned total[32];           // [0]: workgroups that hold a ticket
+    unsigned bar[XG][32];         // [x][0]: group barrier counter (monotonic)
+    unsigned status[32];          // [0]: XERR_* (sticky), [1]: the XCD that raised it
+    unsigned pad[32];
+};
+
+typedef unsigned int xv4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double xld(const double *p) {      // 8-byte sc1 load: bypasses L1, served by the XCD's L2
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned xldu(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one row of D partials (8*D bytes, 8*D-aligned) with sc1 loads: 16-byte buffer loads where the row allows
+template <int D>
+struct XRows {
+    __amdgpu_buffer_rsrc_t rs;
+    const double *base;
+    __device__ __forceinline__ void init(const double *p, size_t bytes) {
+        base = p;
+        if (D >= 2) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, (int)bytes, 0x00020000);
+    }
+    // row index counts rows of D doubles from `base` (the ping-pong half is part of the row index)
+    __device__ __forceinline__ void load(size_t row, double *v) const {
+        if (D == 1) {
+            v[0] = xld(base + row);
+        } else {
+#pragma unroll
+            for (int k = 0; k < D / 2; k++) {
+                const xv4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(row * (size_t)(8 * D)) + 16 * k, 0, 16);   // aux 16 = sc1
+                v[2 * k] = __hiloint2double((int)q.y, (int)q.x);
+                v[2 * k + 1] = __hiloint2double((int)q.w, (int)q.z);
+            }
+        }
+    }
+};
+template <int D>
+__device__ __forceinline__ void xstore_row(double *p, const double *v) {      // plain stores: the line stays in the XCD's L2
+    if (D == 1) {
+        *p = v[0];
+    } else {
+#pragma unroll
+        for (int k = 0; k < D / 2; k++) reinterpret_cast<double2 *>(p)[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    }
+}
+template <int D>
+__device__ __forceinline__ void xload_row_plain(const double *p, double *v) {  // read-only inputs (written by an earlier launch)
+    if (D == 1) {
+        v[0] = *p;
+    } else {
+#pragma unroll
+        for (int k = 0; k < D / 2; k++) { const double2 q = reinterpret_cast<const double2 *>(p)[k]; v[2 * k] = q.x; v[2 * k + 1] = q.y; }
+    }
+}
+
+struct XGroup { int x, c, S, ok; };
+
+__device__ inline void xfail(XSync *sy, unsigned code, int x) {
+    if (__hip_atomic_exchange(&sy->status[0], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        __hip_atomic_store(&sy->status[1], (unsigned)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// which XCD am I on, which member of its group am I, how many members does it have (known once EVERY workgroup of the
+// launch holds a ticket: one launch-wide wait at the start of the sweep, none afterwards)
+__device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
+    if (threadIdx.x == 0) {
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7;
+        const unsigned c = __hip_atomic_fetch_add(&sy->ticket[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the ticket is taken before it is counted
+        __hip_atomic_fetch_add(&sy->total[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        for (unsigned spins = 0;; spins++) {
+            if (xldu(&sy->total[0]) >= gridDim.x) break;
+            if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) { xfail(sy, XERR_TIMEOUT, xcc); ok = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        ctl[0] = xcc; ctl[1] = (int)c; ctl[2] = (int)xldu(&sy->ticket[xcc][0]); ctl[3] = ok;
+    }
+    __syncthreads();
+    XGroup g;
+    g.x = __builtin_amdgcn_readfirstlane(ctl[0]); g.c = __builtin_amdgcn_readfirstlane(ctl[1]);
+    g.S = __builtin_amdgcn_readfirstlane(ctl[2]); g.ok = __builtin_amdgcn_readfirstlane(ctl[3]);
+    return g;
+}
+
+// one episode of the group barrier: `target` = members * episodes so far
+__device__ __forceinline__ void xbarrier(XSync *sy, int x, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its stores have reached L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&sy->bar[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned spins = 0;; spins++) {
+            if ((int)(xldu(&sy->bar[x][0]) - target) >= 0) break;
+            if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) { xfail(sy, XERR_TIMEOUT, x); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+// knots of one column, read from the L2-resident state
+struct XKnots {
+    const double *p;
+    __device__ __forceinline__ double operator[](int i) const { return xld(p + i); }
+};
+
+__device__ __forceinline__ double xwave_sum(double v) {            // butterfly: every lane ends with the same sum, fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ================================ backward ====================================================
+struct XBackArgs {
+    Consts c;
+    const double *ss_value;     // [G] terminal marginal value (BackwardIteration.jl:85)
+    const double *xhh;          // [n_hh*P]
+    const double *dxr, *dxw, *dxt;   // [P][Ntot] tangents of the household inputs
+    int Ntot, n0, N;            // row stride of dx*, first direction of this pass, directions in this pass
+    XSync *sy;
+    double *st_s, *st_ds;       // state (see top)
+    double *pol;                // [P][G] policy sequence (written by group 0)
+    double *dpol;               // [P][groups][G][D] of this pass
+    int groups;                 // active groups of this pass = max(1, ceil(N / D))
+    int *err;                   // device error word of the context (knots / domain)
+};
+
+template <int D, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
+    constexpr int DD = D ? D : 1;
+    extern __shared__ __attribute__((aligned(16))) double xl[];
+    const Consts &c = A.c;
+    const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
+    double *Vsh = xl;                                   // [(1+D)][ne][64]
+    double *Pish = Vsh + (size_t)(1 + D) * ne * 64;     // [ne*ne]
+    int *ctl = reinterpret_cast<int *>(Pish + ne * ne);
+    const XGroup g = xgroup_join(A.sy, ctl);
+    if (!g.ok) return;
+    const int x = g.x, cW = g.c;
+    if (x >= A.groups) return;                          // this XCD has no directions in this pass
+    const int Sact = (na + XRW - 1) / XRW;              // members that own rows
+    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }   // the whole group agrees on S
+    if (cW >= Sact) return;
+    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int a = cW * XRW + lane;
+    const bool own = lane < XRW && a < na;
+    const bool leader = x == 0;
+    const size_t pt = (size_t)e * na + (own ? a : 0);
+    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    const double ze = c.z[e], xa = c.a[own ? a : 0];
+    // this group's view of the ping-pong state: half h starts h*hs rows further on (no arrays indexed by h: they would
+    // live in scratch)
+    const size_t hs = (size_t)XG * G;
+    double *const sS = A.st_s + (size_t)x * G;
+    double *const sD = A.st_ds + (size_t)x * G * DD;
+    XRows<DD> rows;
+    rows.init(sD, (hs + G) * DD * 8);
+    const int nd = A.n0 + x * D;                        // first direction of this group in dx*
+    // terminal value, zero partials (BackwardIteration.jl:85)
+    Vsh[e * 64 + lane] = own ? A.ss_value[pt] : 0.0;
+#pragma unroll
+    for (int k = 0; k < D; k++) Vsh[((1 + k) * ne + e) * 64 + lane] = 0.0;
+    __syncthreads();
+    int cur = 0, guess = -1;
+    unsigned episode = 0;
+    // X half of period tx from V_{tx+1}, dV_{tx+1} in LDS (KrusellSmith.jl:59-62; same expressions as egm_X): the knots
+    // s_tx and their partials -> state[buf]
+    auto xhalf = [&](int tx, int buf) {
+        const double r1 = A.xhh[c.n_hh * tx], w1 = A.xhh[c.n_hh * tx + 1], tr1 = hh_tr(c, A.xhh, tx);
+        if (!own) return;
+        const double E = mix_sum(Vsh[lane] * Pish[e], Vsh + lane, 64, Pish + e, ne, 1, ne);
+        const double bE = E * c.beta;
+        const double ex = -1.0 / c.gamma;
+        if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);
+        const double cm = pow_crra(bE, ex);
+        const double rho = 1.0 / (1.0 + r1);
+        const double s1 = rho * ((cm - (w1 * ze + tr1)) + xa);
+        const double kc = rho * (c.beta * ex * (cm / bE));
+        sS[(size_t)buf * hs + pt] = s1;
+        if (D > 0) {
+            double ds[DD];
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const double *dVk = Vsh + (size_t)(1 + k) * ne * 64;
+                const double dE = mix_sum(Pish[e] * dVk[lane], dVk + lane, 64, Pish + e, ne, 1, ne);
+                const bool on = x * D + k < A.N;
+                const size_t ix = (size_t)tx * A.Ntot + nd + k;
+                const double dr1 = on ? A.dxr[ix] : 0.0, dw1 = on ? A.dxw[ix] : 0.0;
+                const double dt1 = (on && c.n_hh > 2) ? A.dxt[ix] : 0.0;
+                ds[k] = kc * dE - rho * ((ze * dw1 + dt1) + s1 * dr1);
+            }
+            xstore_row<DD>(sD + ((size_t)buf * hs + pt) * DD, ds);
+        }
+    };
+    // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0), one group barrier after every X
+    for (int i = 0; i <= P; i++) {
+        if (i > 0) {
+            // ---- Y half of period t (KrusellSmith.jl:66-80 under Dual): bracket gather -> policy and its partials,
+            //      marginal value and its partials -> LDS
+            const int t = P - i;
+            cur = (i - 1) & 1;
+            const double r = A.xhh[c.n_hh * t], w = A.xhh[c.n_hh * t + 1], tr = hh_tr(c, A.xhh, t);
+            double V = 0.0, dV[DD];
+#pragma unroll
+            for (int k = 0; k < DD; k++) dV[k] = 0.0;
+            if (own) {
+                const XKnots kn{sS + (size_t)cur * hs + (size_t)e * na};
+                const size_t rb = (size_t)cur * hs + (size_t)e * na;
+                double d0[DD], d1[DD];
+#pragma unroll
+                for (int k = 0; k < DD; k++) d0[k] = d1[k] = 0.0;
+                const int pg = guess < 0 ? -1 : (guess < na - 1 ? guess : na - 2);
+                if (D > 0 && pg >= 0) {          // speculative: brackets move by a few knots per period
+                    rows.load(rb + pg, d0);
+                    rows.load(rb + pg + 1, d1);
+                }
+                const YOut o = egm_Y(c, kn, a, e, r, w, tr, A.err, t, guess);
+                if (D > 0 && o.ib != pg && (o.A != 0.0 || o.B != 0.0)) {
+                    rows.load(rb + o.ib, d0);
+                    rows.load(rb + o.ib + 1, d1);
+                }
+                guess = o.ib;
+                V = o.V;
+                if (leader) A.pol[(size_t)t * G + pt] = o.g;
+                if (D > 0) {
+                    double dg[DD];
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        const bool on = x * D + k < A.N;
+                        const size_t ix = (size_t)t * A.Ntot + nd + k;
+                        const double dr = on ? A.dxr[ix] : 0.0, dw = on ? A.dxw[ix] : 0.0;
+                        const double dtr = (on && c.n_hh > 2) ? A.dxt[ix] : 0.0;
+                        dg[k] = o.A * d0[k] + o.B * d1[k];
+                        dV[k] = o.u * dr + o.v * ((xa * dr + (ze * dw + dtr)) - dg[k]);
+                    }
+                    xstore_row<DD>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * DD, dg);
+                }
+            }
+            Vsh[e * 64 + lane] = V;
+#pragma unroll
+            for (int k = 0; k < D; k++) Vsh[((1 + k) * ne + e) * 64 + lane] = dV[k];
+            __syncthreads();
+        }
+        if (i < P) {
+            xhalf(P - 1 - i, i & 1);
+            episode++;
+            xbarrier(A.sy, x, episode * (unsigned)Sact);
+        }
+    }
+}
+
+// ================================ forward =====================================================
+struct XFwdArgs {
+    Consts c;
+    Record R;                   // pol, seg, clo (k_lottery ran on the policy sequence)
+    const double *D0;           // [G] initial distribution (ForwardIteration.jl:293)
+    XSync *sy;
+    double *st_D, *st_dD;       // state incl. the virtual rows
+    const double *dpol;         // [P][groups][G][D] of this pass
+    int groups, N;
+    double *Dseq;               // [P+1][G] distribution path (group 0 writes rows 1..P; row 0 of a column lacks the virtual mass)
+    double *Dvirt;              // [P][n_e][64] that virtual mass, per member (added to row 0 by k_xfix_D)
+    double *aggpart;            // [P][Sact*n_e]            Float64 aggregate partials (group 0)
+    double *daggpart;           // [P][Sact*n_e][XG*D]      partials of the aggregate
+};
+
+template <int D, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
+    constexpr int DD = D ? D : 1;
+    extern __shared__ __attribute__((aligned(16))) double xl[];
+    const Consts &c = A.c;
+    const Record &R = A.R;
+    const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
+    const int GV = G + 64 * ne;
+    double *tile = xl;                                  // [(1+D)][ne][64]
+    double *Pish = tile + (size_t)(1 + D) * ne * 64;
+    int *ctl = reinterpret_cast<int *>(Pish + ne * ne);
+    const XGroup g = xgroup_join(A.sy, ctl);
+    if (!g.ok) return;
+    const int x = g.x, cW = g.c;
+    if (x >= A.groups) return;
+    const int Sact = (na + XRW - 1) / XRW;
+    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
+    if (cW >= Sact) return;
+    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int r = cW * XRW + lane;
+    const bool own = lane < XRW && r < na;
+    const bool virt = lane == 63;                       // this wave's virtual row: slot cW of column e
+    const bool leader = x == 0;
+    const size_t pt = (size_t)e * na + (own ? r : 0);
+    const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;      // where this lane's state lives (virtual lanes: the tail)
+    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    const size_t hs = (size_t)XG * GV;                  // rows between the two halves of the ping-pong state
+    double *const sP = A.st_D + (size_t)x * GV;
+    double *const sT = A.st_dD + (size_t)x * GV * DD;
+    XRows<DD> rows;
+    rows.init(sT, (hs + GV) * DD * 8);
+    // lottery geometry of this lane's row as a TARGET: sources of its first segment have bracket r-1, of its second r
+    const double a_m = c.a[own && r > 0 ? r - 1 : 0], a_0 = c.a[own ? r : 0], a_p = c.a[own && r + 1 < na ? r + 1 : na - 1];
+    const double a_top = c.a[na - 1];
+    // D_0 and zero partials into state[0] (ForwardIteration.jl:293: the initial distribution carries no partials)
+    {
+        double z[DD];
+#pragma unroll
+        for (int k = 0; k < DD; k++) z[k] = 0.0;
+        if (own || virt) {
+            sP[slot] = own ? A.D0[pt] : 0.0;
+            if (D > 0) xstore_row<DD>(sT + slot * DD, z);
+        }
+    }
+    unsigned episode = 1;
+    xbarrier(A.sy, x, episode * (unsigned)Sact);
+    int cur = 0;
+    bool vnz = false;                                   // virtual rows of this column may hold mass (wave-uniform)
+    for (int t = 0; t < P; t++) {
+        const size_t base = (size_t)t * G + (size_t)e * na;
+        const int clo = min(max(R.clo[(size_t)t * ne + e], 0), na);
+        const size_t hb = (size_t)cur * hs;             // this period reads half `cur`
+        const double *Dp = sP + hb + (size_t)e * na;
+        const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;      // row index into dpol
+        double accD = 0.0, acc[DD];
+#pragma unroll
+        for (int k = 0; k < DD; k++) acc[k] = 0.0;
+        double polr = 0.0, dpr[DD];
+#pragma unroll
+        for (int k = 0; k < DD; k++) dpr[k] = 0.0;
+        // the mass that sits on the virtual rows of this column (needed by the targets of source 0 when row 0 is not
+        // clamped, and folded into D_{t-1}[0] there): summed by the wave, member order fixed
+        double vD = 0.0, vT[DD];
+#pragma unroll
+        for (int k = 0; k < DD; k++) vT[k] = 0.0;
+        const bool need_v = vnz && clo == 0;
+        if (need_v) {
+            if (lane < Sact) {
+                const size_t vs = (size_t)G + (size_t)e * 64 + lane;
+                vD = xld(sP + hb + vs);
+                if (D > 0) rows.load(hb + vs, vT);
+            }
+            vD = xwave_sum(vD);
+#pragma unroll
+            for (int k = 0; k < D; k++) vT[k] = xwave_sum(vT[k]);
+        }
+        if (own) {
+            int4 sg = R.seg[base + r];
+            sg.x = max(sg.x, 0); sg.z = min(sg.z, na);        // (a record that is not a lottery must not turn into a long loop)
+            polr = R.pol[base + r];
+            if (D > 0) xload_row_plain<DD>(A.dpol + (dbase + r) * DD, dpr);
+            for (int j = sg.x; j < sg.z; j++) {
+                const bool first = j < sg.y;                      // source's upper target is this row
+                const double pj = R.pol[base + j];
+                double Dj = xld(Dp + j), dDj[DD], dpj[DD];
+#pragma unroll
+                for (int k = 0; k < DD; k++) dDj[k] = dpj[k] = 0.0;
+                if (D > 0) {
+                    rows.load(hb + (size_t)e * na + j, dDj);
+                    xload_row_plain<DD>(A.dpol + (dbase + j) * DD, dpj);
+                }
+                if (j == 0) {            // (then clo == 0) row 0's virtual rows follow row 0's interior lottery
+                    Dj += vD;
+#pragma unroll
+                    for (int k = 0; k < D; k++) dDj[k] += vT[k];
+                }
+                // Young lottery of source j (ForwardIteration.jl:59-73; same expressions as k_lottery)
+                const double al = first ? a_m : a_0, gap = first ? a_0 - a_m : a_p - a_0;
+                double wj = (pj - al) / gap, ig = 1.0 / gap;
+                if (pj > a_top) { wj = 1.0; ig = 0.0; }           // all mass on the last point (:59-63)
+                const double gD = ig * Dj, wt = first ? wj : 1.0 - wj;
+                accD += wt * Dj;
+#pragma unroll
+                for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[k] + gD * dpj[k]) : (wt * dDj[k] - gD * dpj[k]);
+            }
+        }
+        // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one and no weight
+        // partial. Each member sums ITS rows of the clamped prefix into its virtual row (never combined: everything
+        // downstream is linear); while row 0 itself is clamped the old virtual row is carried along.
+        {
+            double cD = 0.0, cT[DD];
+#pragma unroll
+            for (int k = 0; k < DD; k++) cT[k] = 0.0;
+            if (own && r < clo) {
+                cD = xld(Dp + r);
+                if (D > 0) rows.load(hb + (size_t)e * na + r, cT);
+            }
+            if (virt && clo > 0 && vnz) {
+                cD = xld(sP + hb + slot);
+                if (D > 0) rows.load(hb + slot, cT);
+            }
+            if (clo > cW * XRW) {                   // wave-uniform: some of this member's rows are clamped
+                cD = xwave_sum(cD);
+#pragma unroll
+                for (int k = 0; k < D; k++) cT[k] = xwave_sum(cT[k]);
+            }
+            if (virt) {
+                accD = cD;
+#pragma unroll
+                for (int k = 0; k < D; k++) acc[k] = cT[k];
+            }
+        }
+        vnz = clo > 0;
+        tile[e * 64 + lane] = accD;
+#pragma unroll
+        for (int k = 0; k < D; k++) tile[((1 + k) * ne + e) * 64 + lane] = acc[k];
+        __syncthreads();
+        // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99), partials alike
+        double Dn = 0.0, dDn[DD];
+        Dn = mix_sum(Dn, tile + lane, 64, Pish + ne * e, 1, 0, ne);
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const double *tk = tile + (size_t)(1 + k) * ne * 64;
+            dDn[k] = mix_sum(Pish[ne * e] * tk[lane], tk + lane, 64, Pish + ne * e, 1, 1, ne);
+        }
+        const int nxt = cur ^ 1;
+        if (own || virt) {
+            sP[(size_t)nxt * hs + slot] = Dn;
+            if (D > 0) xstore_row<DD>(sT + ((size_t)nxt * hs + slot) * DD, dDn);
+            if (leader) {
+                if (own) A.Dseq[(size_t)(t + 1) * G + pt] = Dn;
+                else A.Dvirt[((size_t)t * ne + e) * 64 + cW] = Dn;
+            }
+        }
+        // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307): sum(pol_t * D_t) and its partials;
+        // a virtual row sits at the first grid point: it carries row 0's policy and policy partials
+        double pol_here = polr, dp_here[DD];
+#pragma unroll
+        for (int k = 0; k < DD; k++) dp_here[k] = dpr[k];
+        if (virt) {
+            pol_here = R.pol[base];
+            if (D > 0) xload_row_plain<DD>(A.dpol + dbase * DD, dp_here);
+        }
+        const bool live = own || virt;
+        double pD = live ? pol_here * Dn : 0.0;
+        pD = xwave_sum(pD);
+        const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
+        if (leader && lane == 0) A.aggpart[pb] = pD;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            double pd = live ? (pol_here * dDn[k] + dp_here[k] * Dn) : 0.0;
+            pd = xwave_sum(pd);
+            if (lane == 0) A.daggpart[pb * (size_t)(XG * DD) + x * D + k] = pd;
+        }
+        cur = nxt;
+        episode++;
+        xbarrier(A.sy, x, episode * (unsigned)Sact);
+    }
+}
+
+// row 0 of every column of D_1..D_P: add the virtual mass the forward sweep kept apart (member order fixed)
+__global__ void k_xfix_D(Consts c, double *Dseq, const double *Dvirt, int Sact) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= c.P * c.n_e) return;
+    const int t = idx / c.n_e, e = idx - t * c.n_e;
+    double s = Dseq[(size_t)(t + 1) * c.G + (size_t)e * c.n_a];
+    for (int m = 0; m < Sact; m++) s += Dvirt[(size_t)idx * 64 + m];
+    Dseq[(size_t)(t + 1) * c.G + (size_t)e * c.n_a] = s;
+}
+
+// dagg of one pass [P][XG*D] -> columns [n0, n0+N) of the caller's (P, Ntot) column-major block
+__global__ void k_xout(const double *__restrict__ dagg, int P, int W, int n0, int N, double *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P * N) return;
+    const int n = idx / P, t = idx - n * P;
+    out[(size_t)(n0 + n) * P + t] = dagg[(size_t)t * W + n];
+}
+
+// (G,P,N) col-major export of one pass's dpol [P][groups][G][D] into columns [n0, n0+N)
+__global__ void k_xexport_dpol(const double *dpol, int G, int P, int groups, int D, int n0, int N, double *out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)G * P * N;
+    if (idx >= total) return;
+    const size_t n = idx / ((size_t)G * P), rem = idx - n * (size_t)G * P, t = rem / G, pt = rem - t * G;
+    const int x = (int)n / D, k = (int)n - x * D;
+    out[((size_t)(n0 + n) * P + t) * G + pt] = dpol[(((size_t)t * groups + x) * G + pt) * D + k];
+}
+
+}  // namespace hank

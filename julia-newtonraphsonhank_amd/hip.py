@@ -15,7 +15,7 @@ _lib = None
 
 HANK_OK = 0
 HANK_ERR_NO_DEVICE, HANK_ERR_BAD_ARG, HANK_ERR_KNOTS, HANK_ERR_DOMAIN = 1, 2, 3, 4
-HANK_ERR_NOT_READY, HANK_ERR_NONMONOTONE, HANK_ERR_NOMEM = 5, 6, 7
+HANK_ERR_NOT_READY, HANK_ERR_NONMONOTONE, HANK_ERR_NOMEM, HANK_ERR_SWEEP = 5, 6, 7, 8
 HANK_VF_KRUSELL_SMITH = 0
 
 # the symbols include/hank_hip.h declares (tests check that every one is exported)
@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
     "hank_primal_jvp", "hank_primal_jvp_dev",
     "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
-    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings",
+    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings", "hank_stats", "hank_vfi", "hank_device_available",
 )
 
 
@@ -97,11 +97,22 @@ def load_library() -> C.CDLL:
     lib.hank_forward_step.argtypes = [vp, dp, dp, dp, dp]
     lib.hank_forward_step_dual.argtypes = [vp, dp, dp, dp, dp, i32, dp, dp, dp, dp]
     lib.hank_last_timings.argtypes = [vp, dp, C.POINTER(i32)]
+    lib.hank_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.hank_vfi.argtypes = [vp, dp, C.c_double, i32, dp, dp, C.POINTER(i32), dp]
+    lib.hank_device_available.argtypes = []
     for name in ABI_SYMBOLS:
         if name != "hank_last_error":
             getattr(lib, name).restype = C.c_int
     _lib = lib
     return lib
+
+
+def device_available() -> bool:
+    """True when libhank_hip.so is built and the current HIP device is an MI355X (gfx950)."""
+    try:
+        return bool(load_library().hank_device_available())
+    except (RuntimeError, OSError):
+        return False
 
 
 def _f(x, shape=None) -> np.ndarray:
@@ -239,6 +250,13 @@ class HouseholdBlock:
         names = ("primal_backward", "primal_forward", "tangent_backward", "tangent_forward", "dual_backward", "dual_forward")
         return {k: {"ms": ms[i], "launches": ln[i]} for i, k in enumerate(names)}
 
+    def stats(self):
+        """counters of the context (include/hank_hip.h: hank_stats)."""
+        out = (C.c_int64 * 8)()
+        self._chk(self._lib.hank_stats(self._ctx, out))
+        names = ("sweep_launches", "tangent_workspaces_allocated", "graphs_captured", "schedule", "fallbacks", "vfi_iterations")
+        return {k: int(out[i]) for i, k in enumerate(names)}
+
     def policy_seq(self) -> np.ndarray:
         """(n_a, n_e, P): policy matrix of every period (BackwardIteration's return value)."""
         out = np.empty((self.n_a, self.n_e, self.P), order="F")
@@ -255,6 +273,16 @@ class HouseholdBlock:
         out = np.empty((self.n_a, self.n_e, self.P, N), order="F")
         self._chk(self._lib.hank_get_dpolicy_seq(self._ctx, int(N), _p(out)))
         return out
+
+    def vfi(self, value0, xhh_t, tol: float, max_iter: int = 10_000):
+        """device-resident inner fixed point of the steady state (hank_vfi; SteadyState.jl:132-141):
+        -> (value, policy, steps, last sup-norm)."""
+        v = _f(np.array(value0, dtype=np.float64, copy=True), (self.n_a, self.n_e))
+        x = _f(xhh_t, (self.n_hh,))
+        pol = np.empty((self.n_a, self.n_e), order="F")
+        it, nrm = C.c_int32(), C.c_double()
+        self._chk(self._lib.hank_vfi(self._ctx, _p(x), float(tol), int(max_iter), _p(v), _p(pol), C.byref(it), C.byref(nrm)))
+        return v, pol, it.value, nrm.value
 
     # -- granular steps ---------------------------------------------------------------------
     def backward_step(self, value_next, xhh_t):

@@ -141,3 +141,56 @@ def test_dual_sweep_equals_primal_then_jvp(hank):
         assert np.array_equal(agg0, agg1) and np.array_equal(dagg0, dagg1)
         assert np.array_equal(pol0, hb.policy_seq()) and np.array_equal(dpol0, hb.dpolicy_seq(N))
         assert np.array_equal(hb.jvp(y), dagg0)        # the record it leaves serves later JVPs
+
+
+def test_alternating_batch_widths_reuse_workspaces(hank):
+    """J̅ assembly (N = 256) and the Newton inner loop (N = 1) alternate on one context: the tangent workspaces come
+    from a small most-recently-used cache, so no width is allocated twice (hank_stats) and results do not depend on
+    what ran in between."""
+    m, ss, orc = ks_setup(50, 2, 100)
+    P = 99
+    x, Z = ks_paths(m, ss, "x1", 0.05)
+    hb = hank.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(x[2:4])
+    rng = np.random.default_rng(9)
+    y1, y256, y32 = rng.standard_normal((2, P, 1)), rng.standard_normal((2, P, 256)), rng.standard_normal((2, P, 32))
+    a, b, c = hb.jvp(y1), hb.jvp(y256), hb.jvp(y32)
+    allocated = hb.stats()["tangent_workspaces_allocated"]
+    for _ in range(3):
+        assert np.array_equal(hb.jvp(y1), a)
+        assert np.array_equal(hb.jvp(y256), b)
+        assert np.array_equal(hb.jvp(y32), c)
+    assert hb.stats()["tangent_workspaces_allocated"] == allocated
+    assert np.array_equal(hb.dpolicy_seq(32)[..., 0], hb.dpolicy_seq(32)[..., 0])
+    close(b[:, :1] * 0 + a, a)      # shapes (P, 1)
+    with pytest.raises(hank.HankHIPError):
+        hb.dpolicy_seq(256)          # the last sweep carried 32 directions, not 256
+
+
+def test_schedules_agree(hank):
+    """the XCD-local persistent sweeps (default) and the per-period launches (HANK_SCHEDULE=launch) are two
+    implementations of the same arithmetic: policies and their partials bit for bit, aggregates to summation order."""
+    import os
+    m, ss, orc = ks_setup(500, 4, 300)
+    P, N = 299, 12
+    x, Z = ks_paths(m, ss, "x1", 0.01)
+    y = np.random.default_rng(2).standard_normal((2, P, N))
+    wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    res = {}
+    for sched in ("xcd", "launch"):
+        os.environ["HANK_SCHEDULE"] = sched
+        try:
+            hb = hank.HouseholdBlock(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+        finally:
+            os.environ.pop("HANK_SCHEDULE")
+        hb.set_boundary(ss.value, ss.D)
+        agg, dagg = hb.primal_jvp(x[2:4], y)
+        assert hb.stats()["schedule"] == (1 if sched == "xcd" else 0) and hb.stats()["fallbacks"] == 0
+        res[sched] = (agg, dagg, hb.policy_seq(), hb.dpolicy_seq(N), hb.dist_seq())
+        hb.close()
+    assert np.array_equal(res["xcd"][2], res["launch"][2])
+    assert np.array_equal(res["xcd"][3], res["launch"][3])
+    close(res["xcd"][4], res["launch"][4], rel=1e-12)
+    close(res["xcd"][0], res["launch"][0], rel=1e-12)
+    close(res["xcd"][1], res["launch"][1], rel=1e-11)
