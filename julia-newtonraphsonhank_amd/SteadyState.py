@@ -73,11 +73,11 @@ class SSAssembler:
         value = self._value_warm if self._value_warm is not None else np.ones((self.endog_dim.n, self.n_exog))
         if self.vfi_on_device:
             from .BackwardIteration import household_block
-            from .hip import KnotsNotSortedError
+            from .hip import DomainError, KnotsNotSortedError
             hb = household_block(model)
             try:
                 v, pol, steps, _ = hb.vfi(value, [xv[k] for k in vf.household_inputs], self.vfi_tol, 10_000)
-            except KnotsNotSortedError as e:      # what the host step raises for find_ss's step halving
+            except (KnotsNotSortedError, DomainError) as e:      # what the host step raises / turns non-finite: find_ss halves the step
                 raise ValueError(str(e)) from e
             self.vfi_steps += steps
             res = {"Value": v, self.endog_dim.policy_var: pol}

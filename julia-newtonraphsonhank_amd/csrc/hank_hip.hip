@@ -961,6 +961,15 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
     return HANK_OK;
 }
 
+#ifdef HANK_XSTAMP
+// dev build: the stamps of the last sweeps (see hank_xsweep.h)
+int hank_debug_stamps(hank_ctx *ctx, unsigned long long *out) {
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    HIPC(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(hank::g_xstamps), sizeof(unsigned long long) * 2 * 2 * XSTAMP_NP * XSTAMP_NS));
+    return HANK_OK;
+}
+#endif
+
 int hank_stats(hank_ctx *ctx, int64_t out[8]) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
     ctx->stats[3] = ctx->schedule;

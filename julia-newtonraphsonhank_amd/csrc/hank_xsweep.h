@@ -92,6 +92,20 @@ __device__ __forceinline__ void xload_row_plain(const double *p, double *v) {  /
 
 struct XGroup { int x, c, S, ok; };
 
+// dev build only (make stamp): s_memtime stamps of lane 0 / wave 0 of the first and last member of group 0, periods
+// [XSTAMP_T0, XSTAMP_T0+8): where a period's time goes. Never compiled into the product library.
+#ifdef HANK_XSTAMP
+constexpr int XSTAMP_T0 = 100, XSTAMP_NP = 8, XSTAMP_NS = 12;
+__device__ unsigned long long g_xstamps[2][2][XSTAMP_NP][XSTAMP_NS];      // [sweep][member first/last][period][stamp]
+#define XSTAMP(sw, on, per, i)                                                                                   \
+    do {                                                                                                         \
+        if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && threadIdx.x == 0)                 \
+            g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memtime();                              \
+    } while (0)
+#else
+#define XSTAMP(sw, on, per, i) do {} while (0)
+#endif
+
 __device__ inline void xfail(XSync *sy, unsigned code, int x) {
     if (__hip_atomic_exchange(&sy->status[0], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
         __hip_atomic_store(&sy->status[1], (unsigned)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -123,9 +137,11 @@ __device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
 }
 
 // one episode of the group barrier: `target` = members * episodes so far
-__device__ __forceinline__ void xbarrier(XSync *sy, int x, unsigned target) {
+__device__ __forceinline__ void xbarrier(XSync *sy, int x, unsigned target, int sw = 0, int son = -1, int sper = -1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its stores have reached L2
+    XSTAMP(sw, son, sper, 8);
     __syncthreads();
+    XSTAMP(sw, son, sper, 9);
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(&sy->bar[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (unsigned spins = 0;; spins++) {
@@ -134,7 +150,9 @@ __device__ __forceinline__ void xbarrier(XSync *sy, int x, unsigned target) {
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    XSTAMP(sw, son, sper, 10);
     __syncthreads();
+    XSTAMP(sw, son, sper, 11);
 }
 
 // knots of one column, read from the L2-resident state
@@ -202,6 +220,8 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     __syncthreads();
     int cur = 0, guess = -1;
     unsigned episode = 0;
+    const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact - 1) ? 1 : -1);
+    (void)son;
     // X half of period tx from V_{tx+1}, dV_{tx+1} in LDS (KrusellSmith.jl:59-62; same expressions as egm_X): the knots
     // s_tx and their partials -> state[buf]
     auto xhalf = [&](int tx, int buf) {
@@ -238,6 +258,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
             //      marginal value and its partials -> LDS
             const int t = P - i;
             cur = (i - 1) & 1;
+            XSTAMP(0, son, t, 0);
             const double r = A.xhh[c.n_hh * t], w = A.xhh[c.n_hh * t + 1], tr = hh_tr(c, A.xhh, t);
             double V = 0.0, dV[DD];
 #pragma unroll
@@ -254,6 +275,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
                     rows.load(rb + pg + 1, d1);
                 }
                 const YOut o = egm_Y(c, kn, a, e, r, w, tr, A.err, t, guess);
+                XSTAMP(0, son, t, 1);
                 if (D > 0 && o.ib != pg && (o.A != 0.0 || o.B != 0.0)) {
                     rows.load(rb + o.ib, d0);
                     rows.load(rb + o.ib + 1, d1);
@@ -278,12 +300,15 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
             Vsh[e * 64 + lane] = V;
 #pragma unroll
             for (int k = 0; k < D; k++) Vsh[((1 + k) * ne + e) * 64 + lane] = dV[k];
+            XSTAMP(0, son, t, 2);
             __syncthreads();
+            XSTAMP(0, son, t, 3);
         }
         if (i < P) {
             xhalf(P - 1 - i, i & 1);
+            XSTAMP(0, son, P - i, 4);
             episode++;
-            xbarrier(A.sy, x, episode * (unsigned)Sact);
+            xbarrier(A.sy, x, episode * (unsigned)Sact, 0, son, P - i);
         }
     }
 }
@@ -350,8 +375,12 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
     unsigned episode = 1;
     xbarrier(A.sy, x, episode * (unsigned)Sact);
     int cur = 0;
-    bool vnz = false;                                   // virtual rows of this column may hold mass (wave-uniform)
+    const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact - 1) ? 1 : -1);
+    (void)son;
+    bool vnz = false;                                   // the virtual rows may hold mass: some column was clamped last period
+                                                        // (the exogenous transition spreads it over every column's virtual rows)
     for (int t = 0; t < P; t++) {
+        XSTAMP(1, son, t, 0);
         const size_t base = (size_t)t * G + (size_t)e * na;
         const int clo = min(max(R.clo[(size_t)t * ne + e], 0), na);
         const size_t hb = (size_t)cur * hs;             // this period reads half `cur`
@@ -409,6 +438,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
                 for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[k] + gD * dpj[k]) : (wt * dDj[k] - gD * dpj[k]);
             }
         }
+        XSTAMP(1, son, t, 1);
         // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one and no weight
         // partial. Each member sums ITS rows of the clamped prefix into its virtual row (never combined: everything
         // downstream is linear); while row 0 itself is clamped the old virtual row is carried along.
@@ -435,11 +465,12 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
                 for (int k = 0; k < D; k++) acc[k] = cT[k];
             }
         }
-        vnz = clo > 0;
+        XSTAMP(1, son, t, 2);
         tile[e * 64 + lane] = accD;
 #pragma unroll
         for (int k = 0; k < D; k++) tile[((1 + k) * ne + e) * 64 + lane] = acc[k];
-        __syncthreads();
+        vnz = __syncthreads_or(clo > 0) != 0;
+        XSTAMP(1, son, t, 3);
         // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99), partials alike
         double Dn = 0.0, dDn[DD];
         Dn = mix_sum(Dn, tile + lane, 64, Pish + ne * e, 1, 0, ne);
@@ -457,6 +488,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
                 else A.Dvirt[((size_t)t * ne + e) * 64 + cW] = Dn;
             }
         }
+        XSTAMP(1, son, t, 4);
         // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307): sum(pol_t * D_t) and its partials;
         // a virtual row sits at the first grid point: it carries row 0's policy and policy partials
         double pol_here = polr, dp_here[DD];
@@ -479,7 +511,8 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
         }
         cur = nxt;
         episode++;
-        xbarrier(A.sy, x, episode * (unsigned)Sact);
+        XSTAMP(1, son, t, 5);
+        xbarrier(A.sy, x, episode * (unsigned)Sact, 1, son, t);
     }
 }
 

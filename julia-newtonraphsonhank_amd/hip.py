@@ -10,7 +10,10 @@ from pathlib import Path
 
 import numpy as np
 
-_LIB_PATH = Path(__file__).resolve().parent / "libhank_hip.so"
+import os
+
+# HANK_HIP_LIB: a dev knob (instrumented builds of the same library, e.g. `make stamp`)
+_LIB_PATH = Path(os.environ.get("HANK_HIP_LIB") or Path(__file__).resolve().parent / "libhank_hip.so")
 _lib = None
 
 HANK_OK = 0

@@ -6,6 +6,9 @@ import time
 from pathlib import Path
 
 import numpy as np
+import torch
+
+torch.cuda.init()       # before libhank_hip loads its HIP runtime (the other order leaves torch without a device)
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
@@ -53,7 +56,6 @@ def parity(n_a, n_e, T, N, shock=0.05, pols=True):
 
 
 def timing(n_a, n_e, T, Ns):
-    import torch
     m, ss, _ = ks_setup(n_a, n_e, T)
     P = T - 1
     x, Z = ks_paths(m, ss, "x1", 0.01)
