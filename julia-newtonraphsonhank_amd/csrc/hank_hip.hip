@@ -72,7 +72,7 @@ struct XWork {
     int grid = 0, Sact = 0, maxt = 768, dmax = XD_MAX;
     XSync *sync = nullptr;          // [2 * XPASS_MAX]: backward and forward sweep of every pass
     double *st_s = nullptr, *st_ds = nullptr, *st_D = nullptr, *st_dD = nullptr;
-    double *Dvirt = nullptr, *aggpart = nullptr;
+    double *Dvirt = nullptr, *aggpart = nullptr, *rho = nullptr;
     std::list<XTan> tans;           // most recently used first
     int last_passes = 0;            // sync blocks the last call used (their status words are checked)
 };
@@ -398,7 +398,7 @@ static void x_free(hank_ctx *ctx) {
     X.tans.clear();
     ctx->xcur = nullptr;
     (void)hipFree(X.sync); (void)hipFree(X.st_s); (void)hipFree(X.st_ds); (void)hipFree(X.st_D); (void)hipFree(X.st_dD);
-    (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart);
+    (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart); (void)hipFree(X.rho);
     X = XWork();
 }
 
@@ -410,8 +410,9 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, hipGetDeviceProperties(&prop, ctx->device));
     X.grid = (prop.multiProcessorCount / XG) * XG;
     X.Sact = (c.n_a + XRW - 1) / XRW;
-    X.maxt = c.n_e <= 12 ? 768 : 1024;      // 64*n_e threads per workgroup; the register budget follows the bound
-    X.dmax = c.n_e <= 12 ? XD_MAX : 2;
+    // 64*n_e threads per workgroup (+ one run-ahead wave in the forward sweep); the register budget follows the bound
+    X.maxt = 64 * (c.n_e + 1) <= 768 ? 768 : 1024;
+    X.dmax = X.maxt == 768 ? XD_MAX : 2;
     const size_t G = c.G, GV = G + 64 * (size_t)c.n_e, P = c.P;
     HIPC(ctx, dmalloc(&X.sync, (size_t)2 * XPASS_MAX));
     HIPC(ctx, dmalloc(&X.st_s, 2 * XG * G));
@@ -420,6 +421,7 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.st_dD, 2 * XG * GV * X.dmax));
     HIPC(ctx, dmalloc(&X.Dvirt, P * c.n_e * 64));
     HIPC(ctx, dmalloc(&X.aggpart, P * (size_t)X.Sact * c.n_e));
+    HIPC(ctx, dmalloc(&X.rho, P));
     HIPC(ctx, hipMemset(X.Dvirt, 0, sizeof(double) * P * c.n_e * 64));
     X.ready = true;
     return HANK_OK;
@@ -468,6 +470,8 @@ static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
     return HANK_OK;
 }
 
+static int x_slots(int D) { return D == 0 ? 1 : (D == 1 ? 2 : (D == 2 ? 4 : 6)); }     // XTile<D>::SL
+
 template <int MAXT>
 static void x_launch(int D, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XBackArgs &ab, const XFwdArgs &af) {
 #define XL(DV)                                                                                       \
@@ -501,9 +505,11 @@ static int x_run(hank_ctx *ctx, XTan *w) {
     const int N = w ? w->N : 0;
     if (w) hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
     const dim3 grd(X.grid), blk(64 * c.n_e);
+    const dim3 blkf(64 * (c.n_e + 1) <= X.maxt ? 64 * (c.n_e + 1) : 64 * c.n_e);     // + the run-ahead wave where it fits
     XBackArgs ab{};
     ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.Ntot = N > 0 ? N : 1;
-    ab.st_s = X.st_s; ab.st_ds = X.st_ds; ab.pol = ctx->R.pol; ab.err = ctx->d_err;
+    ab.st_s = X.st_s; ab.st_ds = X.st_ds; ab.pol = ctx->R.pol; ab.err = ctx->d_err; ab.rho = X.rho;
+    hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
     XFwdArgs af{};
     af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.st_D = X.st_D; af.st_dD = X.st_dD;
     af.Dseq = ctx->R.Dseq; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart;
@@ -513,7 +519,7 @@ static int x_run(hank_ctx *ctx, XTan *w) {
         ab.dxr = w ? w->dxr : nullptr; ab.dxw = w ? w->dxw : nullptr; ab.dxt = w ? w->dxt : nullptr;
         ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 * p;
         ab.dpol = w ? w->dpol + ps.dpol_off : nullptr;
-        const size_t lds = sizeof(double) * ((size_t)(1 + ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e) + 64;
+        const size_t lds = sizeof(double) * ((size_t)x_slots(ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e) + 64;
         if (X.maxt == 768) x_launch<768>(ps.D, true, grd, blk, lds, s, ab, af);
         else x_launch<1024>(ps.D, true, grd, blk, lds, s, ab, af);
         ctx->stats[0]++;
@@ -526,9 +532,9 @@ static int x_run(hank_ctx *ctx, XTan *w) {
         const XPass &ps = passes[p];
         af.sy = X.sync + 2 * p + 1; af.groups = ps.groups; af.N = ps.N;
         af.dpol = w ? w->dpol + ps.dpol_off : nullptr; af.daggpart = w ? w->daggpart : nullptr;
-        const size_t lds = sizeof(double) * ((size_t)(1 + ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e) + 64;
-        if (X.maxt == 768) x_launch<768>(ps.D, false, grd, blk, lds, s, ab, af);
-        else x_launch<1024>(ps.D, false, grd, blk, lds, s, ab, af);
+        const size_t lds = sizeof(double) * ((size_t)x_slots(ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e) + 64;
+        if (X.maxt == 768) x_launch<768>(ps.D, false, grd, blkf, lds, s, ab, af);
+        else x_launch<1024>(ps.D, false, grd, blkf, lds, s, ab, af);
         ctx->stats[0]++;
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[12], s));
         if (w) {

@@ -33,10 +33,10 @@ constexpr int XRW = 63;           // wealth rows per workgroup; lane 63 of every
 constexpr unsigned XSPIN_LIMIT = 1u << 21;
 enum { XERR_TIMEOUT = 1, XERR_PLACEMENT = 2 };
 
-struct XSync {                    // zeroed by a memset node before EVERY launch (2560 B, a multiple of 16)
+struct XSync {                    // zeroed by a memset node before EVERY launch (3456 B, a multiple of 16)
     unsigned ticket[XG][32];      // [x][0]: workgroups that arrived on XCD x (one 128-B line each)
     unsigned total[32];           // [0]: workgroups that hold a ticket
-    unsigned bar[XG][32];         // [x][0]: group barrier counter (monotonic)
+    unsigned flag[XG][64];        // [x][c]: the last barrier episode member c of group x has reached
     unsigned status[32];          // [0]: XERR_* (sticky), [1]: the XCD that raised it
     unsigned pad[32];
 };
@@ -136,17 +136,25 @@ __device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
     return g;
 }
 
-// one episode of the group barrier: `target` = members * episodes so far
-__device__ __forceinline__ void xbarrier(XSync *sy, int x, unsigned target, int sw = 0, int son = -1, int sper = -1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave: its stores have reached L2
+// one episode of the group barrier. No atomics (they execute at the memory side, a fabric round trip each): member c
+// publishes the episode number in ITS word of the group's flag line with a plain store — the line lives in the XCD's
+// L2 like the state itself — and wave 0 of every member polls all members' words with ONE sc1 load per trip.
+// `drain` = false only for a wave that has stored nothing since the last episode (the run-ahead wave: its loads stay in
+// flight across the barrier).
+__device__ __forceinline__ void xbarrier(XSync *sy, int x, int c, int members, unsigned episode, int sw = 0, int son = -1, int sper = -1, bool drain = true) {
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave: its stores have reached L2
     XSTAMP(sw, son, sper, 8);
     __syncthreads();
     XSTAMP(sw, son, sper, 9);
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&sy->bar[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c]) = episode;
         for (unsigned spins = 0;; spins++) {
-            if ((int)(xldu(&sy->bar[x][0]) - target) >= 0) break;
-            if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) { xfail(sy, XERR_TIMEOUT, x); break; }
+            const unsigned f = (int)threadIdx.x < members ? xldu(&sy->flag[x][threadIdx.x]) : episode;
+            if (__all((int)(f - episode) >= 0)) break;
+            if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
+                if (threadIdx.x == 0) xfail(sy, XERR_TIMEOUT, x);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
     }
@@ -167,11 +175,58 @@ __device__ __forceinline__ double xwave_sum(double v) {            // butterfly:
     return v;
 }
 
+// sum over the 64 lanes with DPP moves (no LDS traffic), fixed order; the result is valid in lane 63 ONLY
+template <int CTRL, int RM, int BM>
+__device__ __forceinline__ double xdpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, RM, BM, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, RM, BM, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xwave_reduce63(double v) {
+    double s = v + xdpp<0x111, 0xf, 0xf>(v);     // row_shr:1
+    s = s + xdpp<0x112, 0xf, 0xf>(v);            // row_shr:2
+    s = s + xdpp<0x113, 0xf, 0xf>(v);            // row_shr:3
+    s = s + xdpp<0x114, 0xf, 0xe>(s);            // row_shr:4, banks 1..3
+    s = s + xdpp<0x118, 0xf, 0xc>(s);            // row_shr:8, banks 2..3
+    s = s + xdpp<0x142, 0xa, 0xf>(s);            // row_bcast:15 into rows 1 and 3
+    s = s + xdpp<0x143, 0xc, 0xf>(s);            // row_bcast:31 into rows 2 and 3
+    return s;
+}
+
+// The LDS tile of the n_e-wide mixing: [column k][lane][slot], slot 0 = the value, 1..D = the partials, padded to an
+// even count SL so that a lane's slots are one run of 16-byte pieces (ds_read/write_b128; lane stride 8*SL bytes is
+// conflict-free for SL = 2, 4, 6). One pass over k serves the value and every partial.
+template <int D> struct XTile { static constexpr int SL = D == 0 ? 1 : (D == 1 ? 2 : (D == 2 ? 4 : (D == 4 ? 6 : D + 2))); };
+template <int SL>
+__device__ __forceinline__ void xtile_store(double *t, const double *v) {
+    if (SL == 1) { t[0] = v[0]; return; }
+#pragma unroll
+    for (int q = 0; q < SL / 2; q++) reinterpret_cast<double2 *>(t)[q] = make_double2(v[2 * q], v[2 * q + 1]);
+}
+// out[s] = sum_k P[k*ps] * tile[k][lane][s], k ascending, first term unrounded-added (same order as mix_sum)
+template <int SL, int NS>
+__device__ __forceinline__ void xtile_mix(const double *tl, const double *P, int ps, int ne, double *out) {
+    const int ks = 64 * SL;
+#pragma unroll 4
+    for (int k = 0; k < ne; k++) {
+        double v[SL];
+        if (SL == 1) v[0] = tl[(size_t)k * ks];
+        else {
+#pragma unroll
+            for (int q = 0; q < SL / 2; q++) { const double2 d = reinterpret_cast<const double2 *>(tl + (size_t)k * ks)[q]; v[2 * q] = d.x; v[2 * q + 1] = d.y; }
+        }
+        const double p = P[k * ps];
+#pragma unroll
+        for (int q = 0; q < NS; q++) out[q] = k == 0 ? p * v[q] : out[q] + p * v[q];
+    }
+}
+
 // ================================ backward ====================================================
 struct XBackArgs {
     Consts c;
     const double *ss_value;     // [G] terminal marginal value (BackwardIteration.jl:85)
     const double *xhh;          // [n_hh*P]
+    const double *rho;          // [P] 1/(1+r_t)
     const double *dxr, *dxw, *dxt;   // [P][Ntot] tangents of the household inputs
     int Ntot, n0, N;            // row stride of dx*, first direction of this pass, directions in this pass
     XSync *sy;
@@ -188,8 +243,9 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
-    double *Vsh = xl;                                   // [(1+D)][ne][64]
-    double *Pish = Vsh + (size_t)(1 + D) * ne * 64;     // [ne*ne]
+    constexpr int SL = XTile<D>::SL;
+    double *Vsh = xl;                                   // [ne][64][SL]
+    double *Pish = Vsh + (size_t)SL * ne * 64;          // [ne*ne]
     int *ctl = reinterpret_cast<int *>(Pish + ne * ne);
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
@@ -213,10 +269,15 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     XRows<DD> rows;
     rows.init(sD, (hs + G) * DD * 8);
     const int nd = A.n0 + x * D;                        // first direction of this group in dx*
+    double *const myt = Vsh + ((size_t)e * 64 + lane) * SL;      // this lane's slots in the tile
     // terminal value, zero partials (BackwardIteration.jl:85)
-    Vsh[e * 64 + lane] = own ? A.ss_value[pt] : 0.0;
+    {
+        double v0[SL];
 #pragma unroll
-    for (int k = 0; k < D; k++) Vsh[((1 + k) * ne + e) * 64 + lane] = 0.0;
+        for (int q = 0; q < SL; q++) v0[q] = 0.0;
+        v0[0] = own ? A.ss_value[pt] : 0.0;
+        xtile_store<SL>(myt, v0);
+    }
     __syncthreads();
     int cur = 0, guess = -1;
     unsigned episode = 0;
@@ -225,14 +286,16 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     // X half of period tx from V_{tx+1}, dV_{tx+1} in LDS (KrusellSmith.jl:59-62; same expressions as egm_X): the knots
     // s_tx and their partials -> state[buf]
     auto xhalf = [&](int tx, int buf) {
-        const double r1 = A.xhh[c.n_hh * tx], w1 = A.xhh[c.n_hh * tx + 1], tr1 = hh_tr(c, A.xhh, tx);
+        const double w1 = A.xhh[c.n_hh * tx + 1], tr1 = hh_tr(c, A.xhh, tx);
         if (!own) return;
-        const double E = mix_sum(Vsh[lane] * Pish[e], Vsh + lane, 64, Pish + e, ne, 1, ne);
+        double mx[1 + D];                                  // E and dE_k: one pass over the tile
+        xtile_mix<SL, 1 + D>(Vsh + (size_t)lane * SL, Pish + e, ne, ne, mx);
+        const double E = mx[0];
         const double bE = E * c.beta;
         const double ex = -1.0 / c.gamma;
         if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);
         const double cm = pow_crra(bE, ex);
-        const double rho = 1.0 / (1.0 + r1);
+        const double rho = A.rho[tx];                      // 1/(1+r_tx), once per period (k_xrho), not once per thread
         const double s1 = rho * ((cm - (w1 * ze + tr1)) + xa);
         const double kc = rho * (c.beta * ex * (cm / bE));
         sS[(size_t)buf * hs + pt] = s1;
@@ -240,8 +303,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
             double ds[DD];
 #pragma unroll
             for (int k = 0; k < D; k++) {
-                const double *dVk = Vsh + (size_t)(1 + k) * ne * 64;
-                const double dE = mix_sum(Pish[e] * dVk[lane], dVk + lane, 64, Pish + e, ne, 1, ne);
+                const double dE = mx[1 + k];
                 const bool on = x * D + k < A.N;
                 const size_t ix = (size_t)tx * A.Ntot + nd + k;
                 const double dr1 = on ? A.dxr[ix] : 0.0, dw1 = on ? A.dxw[ix] : 0.0;
@@ -297,9 +359,15 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
                     xstore_row<DD>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * DD, dg);
                 }
             }
-            Vsh[e * 64 + lane] = V;
+            {
+                double vs[SL];
 #pragma unroll
-            for (int k = 0; k < D; k++) Vsh[((1 + k) * ne + e) * 64 + lane] = dV[k];
+                for (int q = 0; q < SL; q++) vs[q] = 0.0;
+                vs[0] = V;
+#pragma unroll
+                for (int k = 0; k < D; k++) vs[1 + k] = dV[k];
+                xtile_store<SL>(myt, vs);
+            }
             XSTAMP(0, son, t, 2);
             __syncthreads();
             XSTAMP(0, son, t, 3);
@@ -308,7 +376,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
             xhalf(P - 1 - i, i & 1);
             XSTAMP(0, son, P - i, 4);
             episode++;
-            xbarrier(A.sy, x, episode * (unsigned)Sact, 0, son, P - i);
+            xbarrier(A.sy, x, cW, Sact, episode, 0, son, P - i);
         }
     }
 }
@@ -331,13 +399,14 @@ struct XFwdArgs {
 template <int D, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
     constexpr int DD = D ? D : 1;
+    constexpr int SL = XTile<D>::SL;
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const Record &R = A.R;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     const int GV = G + 64 * ne;
-    double *tile = xl;                                  // [(1+D)][ne][64]
-    double *Pish = tile + (size_t)(1 + D) * ne * 64;
+    double *tile = xl;                                  // [ne][64][SL]
+    double *Pish = tile + (size_t)SL * ne * 64;
     int *ctl = reinterpret_cast<int *>(Pish + ne * ne);
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
@@ -346,10 +415,16 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
     const int Sact = (na + XRW - 1) / XRW;
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
-    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
-    const int r = cW * XRW + lane;
-    const bool own = lane < XRW && r < na;
-    const bool virt = lane == 63;                       // this wave's virtual row: slot cW of column e
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // wave n_e (when the block has one) is the RUN-AHEAD wave: it only touches next period's record and policy-partial
+    // lines of this member's rows, so that every compute wave of the XCD finds them in L2 (its loads wait on its own
+    // counter, not on the compute waves')
+    const bool runahead = wv >= ne;
+    const int e = runahead ? 0 : wv;
+    const int r0 = cW * XRW;
+    const int r = r0 + lane;
+    const bool own = !runahead && lane < XRW && r < na;
+    const bool virt = !runahead && lane == 63;          // this wave's virtual row: slot cW of column e
     const bool leader = x == 0;
     const size_t pt = (size_t)e * na + (own ? r : 0);
     const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;      // where this lane's state lives (virtual lanes: the tail)
@@ -359,6 +434,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
     double *const sT = A.st_dD + (size_t)x * GV * DD;
     XRows<DD> rows;
     rows.init(sT, (hs + GV) * DD * 8);
+    double *const myt = tile + ((size_t)e * 64 + lane) * SL;
     // lottery geometry of this lane's row as a TARGET: sources of its first segment have bracket r-1, of its second r
     const double a_m = c.a[own && r > 0 ? r - 1 : 0], a_0 = c.a[own ? r : 0], a_p = c.a[own && r + 1 < na ? r + 1 : na - 1];
     const double a_top = c.a[na - 1];
@@ -373,147 +449,196 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
         }
     }
     unsigned episode = 1;
-    xbarrier(A.sy, x, episode * (unsigned)Sact);
+    xbarrier(A.sy, x, cW, Sact, episode);
     int cur = 0;
     const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact - 1) ? 1 : -1);
     (void)son;
     bool vnz = false;                                   // the virtual rows may hold mass: some column was clamped last period
                                                         // (the exogenous transition spreads it over every column's virtual rows)
+    constexpr int NRA = MAXT == 768 ? 11 : 15;          // columns a block with a run-ahead wave can have
+    int touched[NRA], sink_i = 0;                       // the run-ahead wave's loads, consumed a period later
+#pragma unroll
+    for (int ee = 0; ee < NRA; ee++) touched[ee] = 0;
     for (int t = 0; t < P; t++) {
         XSTAMP(1, son, t, 0);
         const size_t base = (size_t)t * G + (size_t)e * na;
-        const int clo = min(max(R.clo[(size_t)t * ne + e], 0), na);
         const size_t hb = (size_t)cur * hs;             // this period reads half `cur`
-        const double *Dp = sP + hb + (size_t)e * na;
         const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;      // row index into dpol
-        double accD = 0.0, acc[DD];
+        int clo = 0;
+        double accD = 0.0, acc[DD], polr = 0.0, dpr[DD];
 #pragma unroll
-        for (int k = 0; k < DD; k++) acc[k] = 0.0;
-        double polr = 0.0, dpr[DD];
+        for (int k = 0; k < DD; k++) acc[k] = dpr[k] = 0.0;
+        if (runahead) {
+            // consume what was touched one period ago (long landed: no wait), then touch period t+1: per column one
+            // wave-instruction, a dword every 64 bytes of this member's seg (16 lanes), pol (8) and dpol (8*D) runs
 #pragma unroll
-        for (int k = 0; k < DD; k++) dpr[k] = 0.0;
-        // the mass that sits on the virtual rows of this column (needed by the targets of source 0 when row 0 is not
-        // clamped, and folded into D_{t-1}[0] there): summed by the wave, member order fixed
-        double vD = 0.0, vT[DD];
+            for (int ee = 0; ee < NRA; ee++) sink_i ^= touched[ee];
+            if (t + 1 < P) {
+                const int rows_here = min(XRW, na - r0);
+                const char *p = nullptr;
+                int off = 0, len = 0;
+                if (lane < 16) { off = lane * 64; len = rows_here * 16; }
+                else if (lane < 24) { off = (lane - 16) * 64; len = rows_here * 8; }
+                else if (lane < 24 + 8 * D) { off = (lane - 24) * 64; len = rows_here * 8 * D; }
 #pragma unroll
-        for (int k = 0; k < DD; k++) vT[k] = 0.0;
-        const bool need_v = vnz && clo == 0;
-        if (need_v) {
-            if (lane < Sact) {
-                const size_t vs = (size_t)G + (size_t)e * 64 + lane;
-                vD = xld(sP + hb + vs);
-                if (D > 0) rows.load(hb + vs, vT);
-            }
-            vD = xwave_sum(vD);
-#pragma unroll
-            for (int k = 0; k < D; k++) vT[k] = xwave_sum(vT[k]);
-        }
-        if (own) {
-            int4 sg = R.seg[base + r];
-            sg.x = max(sg.x, 0); sg.z = min(sg.z, na);        // (a record that is not a lottery must not turn into a long loop)
-            polr = R.pol[base + r];
-            if (D > 0) xload_row_plain<DD>(A.dpol + (dbase + r) * DD, dpr);
-            for (int j = sg.x; j < sg.z; j++) {
-                const bool first = j < sg.y;                      // source's upper target is this row
-                const double pj = R.pol[base + j];
-                double Dj = xld(Dp + j), dDj[DD], dpj[DD];
-#pragma unroll
-                for (int k = 0; k < DD; k++) dDj[k] = dpj[k] = 0.0;
-                if (D > 0) {
-                    rows.load(hb + (size_t)e * na + j, dDj);
-                    xload_row_plain<DD>(A.dpol + (dbase + j) * DD, dpj);
+                for (int ee = 0; ee < NRA; ee++) {
+                    if (ee < ne) {
+                        const size_t el = (size_t)(t + 1) * G + (size_t)ee * na + r0;
+                        if (lane < 16) p = reinterpret_cast<const char *>(R.seg + el);
+                        else if (lane < 24) p = reinterpret_cast<const char *>(R.pol + el);
+                        else p = reinterpret_cast<const char *>(A.dpol + (((size_t)(t + 1) * A.groups + x) * G + (size_t)ee * na + r0) * DD);
+                        if (off < len) touched[ee] = *reinterpret_cast<const int *>(p + off);
+                    }
                 }
-                if (j == 0) {            // (then clo == 0) row 0's virtual rows follow row 0's interior lottery
-                    Dj += vD;
+            }
+        } else {
+            clo = min(max(R.clo[(size_t)t * ne + e], 0), na);
+            const double *Dp = sP + hb + (size_t)e * na;
+            // the mass that sits on the virtual rows of this column (needed by the targets of source 0 when row 0 is not
+            // clamped, and folded into D_{t-1}[0] there): summed by the wave, member order fixed
+            double vD = 0.0, vT[DD];
 #pragma unroll
-                    for (int k = 0; k < D; k++) dDj[k] += vT[k];
+            for (int k = 0; k < DD; k++) vT[k] = 0.0;
+            if (vnz && clo == 0) {
+                if (lane < Sact) {
+                    const size_t vs = (size_t)G + (size_t)e * 64 + lane;
+                    vD = xld(sP + hb + vs);
+                    if (D > 0) rows.load(hb + vs, vT);
                 }
-                // Young lottery of source j (ForwardIteration.jl:59-73; same expressions as k_lottery)
-                const double al = first ? a_m : a_0, gap = first ? a_0 - a_m : a_p - a_0;
-                double wj = (pj - al) / gap, ig = 1.0 / gap;
-                if (pj > a_top) { wj = 1.0; ig = 0.0; }           // all mass on the last point (:59-63)
-                const double gD = ig * Dj, wt = first ? wj : 1.0 - wj;
-                accD += wt * Dj;
+                vD = xwave_sum(vD);
 #pragma unroll
-                for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[k] + gD * dpj[k]) : (wt * dDj[k] - gD * dpj[k]);
+                for (int k = 0; k < D; k++) vT[k] = xwave_sum(vT[k]);
             }
+            if (own) {
+                int4 sg = R.seg[base + r];
+                sg.x = max(sg.x, 0); sg.z = min(sg.z, na);        // (a record that is not a lottery must not turn into a long loop)
+                polr = R.pol[base + r];
+                if (D > 0) xload_row_plain<DD>(A.dpol + (dbase + r) * DD, dpr);
+                // sources two at a time: both sources' loads are in flight before either is used
+                for (int j0 = sg.x; j0 < sg.z; j0 += 2) {
+                    double pj[2], Dj[2], dDj[2][DD], dpj[2][DD];
+                    bool on[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int j = j0 + u;
+                        on[u] = j < sg.z;
+                        pj[u] = 0.0; Dj[u] = 0.0;
+#pragma unroll
+                        for (int k = 0; k < DD; k++) dDj[u][k] = dpj[u][k] = 0.0;
+                        if (on[u]) {
+                            pj[u] = R.pol[base + j];
+                            Dj[u] = xld(Dp + j);
+                            if (D > 0) {
+                                rows.load(hb + (size_t)e * na + j, dDj[u]);
+                                xload_row_plain<DD>(A.dpol + (dbase + j) * DD, dpj[u]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int j = j0 + u;
+                        if (!on[u]) continue;
+                        const bool first = j < sg.y;                      // source's upper target is this row
+                        if (j == 0) {            // (then clo == 0) row 0's virtual rows follow row 0's interior lottery
+                            Dj[u] += vD;
+#pragma unroll
+                            for (int k = 0; k < D; k++) dDj[u][k] += vT[k];
+                        }
+                        // Young lottery of source j (ForwardIteration.jl:59-73; same expressions as k_lottery)
+                        const double al = first ? a_m : a_0, gap = first ? a_0 - a_m : a_p - a_0;
+                        double wj = (pj[u] - al) / gap, ig = 1.0 / gap;
+                        if (pj[u] > a_top) { wj = 1.0; ig = 0.0; }        // all mass on the last point (:59-63)
+                        const double gD = ig * Dj[u], wt = first ? wj : 1.0 - wj;
+                        accD += wt * Dj[u];
+#pragma unroll
+                        for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[u][k] + gD * dpj[u][k]) : (wt * dDj[u][k] - gD * dpj[u][k]);
+                    }
+                }
+            }
+            XSTAMP(1, son, t, 1);
+            // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one and no weight
+            // partial. Each member sums ITS rows of the clamped prefix into its virtual row (never combined: everything
+            // downstream is linear); while row 0 itself is clamped the old virtual row is carried along.
+            {
+                double cD = 0.0, cT[DD];
+#pragma unroll
+                for (int k = 0; k < DD; k++) cT[k] = 0.0;
+                if (own && r < clo) {
+                    cD = xld(Dp + r);
+                    if (D > 0) rows.load(hb + (size_t)e * na + r, cT);
+                }
+                if (virt && clo > 0 && vnz) {
+                    cD = xld(sP + hb + slot);
+                    if (D > 0) rows.load(hb + slot, cT);
+                }
+                if (clo > r0) {                     // wave-uniform: some of this member's rows are clamped (lane 63 takes the sum)
+                    cD = xwave_reduce63(cD);
+#pragma unroll
+                    for (int k = 0; k < D; k++) cT[k] = xwave_reduce63(cT[k]);
+                }
+                if (virt) {
+                    accD = cD;
+#pragma unroll
+                    for (int k = 0; k < D; k++) acc[k] = cT[k];
+                }
+            }
+            XSTAMP(1, son, t, 2);
+            double vs[SL];
+#pragma unroll
+            for (int q = 0; q < SL; q++) vs[q] = 0.0;
+            vs[0] = accD;
+#pragma unroll
+            for (int k = 0; k < D; k++) vs[1 + k] = acc[k];
+            xtile_store<SL>(myt, vs);
         }
-        XSTAMP(1, son, t, 1);
-        // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one and no weight
-        // partial. Each member sums ITS rows of the clamped prefix into its virtual row (never combined: everything
-        // downstream is linear); while row 0 itself is clamped the old virtual row is carried along.
-        {
-            double cD = 0.0, cT[DD];
-#pragma unroll
-            for (int k = 0; k < DD; k++) cT[k] = 0.0;
-            if (own && r < clo) {
-                cD = xld(Dp + r);
-                if (D > 0) rows.load(hb + (size_t)e * na + r, cT);
-            }
-            if (virt && clo > 0 && vnz) {
-                cD = xld(sP + hb + slot);
-                if (D > 0) rows.load(hb + slot, cT);
-            }
-            if (clo > cW * XRW) {                   // wave-uniform: some of this member's rows are clamped
-                cD = xwave_sum(cD);
-#pragma unroll
-                for (int k = 0; k < D; k++) cT[k] = xwave_sum(cT[k]);
-            }
-            if (virt) {
-                accD = cD;
-#pragma unroll
-                for (int k = 0; k < D; k++) acc[k] = cT[k];
-            }
-        }
-        XSTAMP(1, son, t, 2);
-        tile[e * 64 + lane] = accD;
-#pragma unroll
-        for (int k = 0; k < D; k++) tile[((1 + k) * ne + e) * 64 + lane] = acc[k];
         vnz = __syncthreads_or(clo > 0) != 0;
         XSTAMP(1, son, t, 3);
-        // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99), partials alike
-        double Dn = 0.0, dDn[DD];
-        Dn = mix_sum(Dn, tile + lane, 64, Pish + ne * e, 1, 0, ne);
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            const double *tk = tile + (size_t)(1 + k) * ne * 64;
-            dDn[k] = mix_sum(Pish[ne * e] * tk[lane], tk + lane, 64, Pish + ne * e, 1, 1, ne);
-        }
         const int nxt = cur ^ 1;
-        if (own || virt) {
-            sP[(size_t)nxt * hs + slot] = Dn;
-            if (D > 0) xstore_row<DD>(sT + ((size_t)nxt * hs + slot) * DD, dDn);
-            if (leader) {
-                if (own) A.Dseq[(size_t)(t + 1) * G + pt] = Dn;
-                else A.Dvirt[((size_t)t * ne + e) * 64 + cW] = Dn;
+        if (!runahead) {
+            // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99), partials alike
+            double mx[1 + D];
+            xtile_mix<SL, 1 + D>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
+            const double Dn = mx[0];
+            if (own || virt) {
+                sP[(size_t)nxt * hs + slot] = Dn;
+                if (D > 0) xstore_row<DD>(sT + ((size_t)nxt * hs + slot) * DD, mx + 1);
+                if (leader) {
+                    if (own) A.Dseq[(size_t)(t + 1) * G + pt] = Dn;
+                    else A.Dvirt[((size_t)t * ne + e) * 64 + cW] = Dn;
+                }
             }
-        }
-        XSTAMP(1, son, t, 4);
-        // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307): sum(pol_t * D_t) and its partials;
-        // a virtual row sits at the first grid point: it carries row 0's policy and policy partials
-        double pol_here = polr, dp_here[DD];
+            XSTAMP(1, son, t, 4);
+            // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307): sum(pol_t * D_t) and its partials;
+            // a virtual row sits at the first grid point: it carries row 0's policy and policy partials
+            double pol_here = polr, dp_here[DD];
 #pragma unroll
-        for (int k = 0; k < DD; k++) dp_here[k] = dpr[k];
-        if (virt) {
-            pol_here = R.pol[base];
-            if (D > 0) xload_row_plain<DD>(A.dpol + dbase * DD, dp_here);
-        }
-        const bool live = own || virt;
-        double pD = live ? pol_here * Dn : 0.0;
-        pD = xwave_sum(pD);
-        const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
-        if (leader && lane == 0) A.aggpart[pb] = pD;
+            for (int k = 0; k < DD; k++) dp_here[k] = dpr[k];
+            if (virt) {
+                pol_here = R.pol[base];
+                if (D > 0) xload_row_plain<DD>(A.dpol + dbase * DD, dp_here);
+            }
+            const bool live = own || virt;
+            const double pD = xwave_reduce63(live ? pol_here * Dn : 0.0);
+            const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
+            if (leader && lane == 63) A.aggpart[pb] = pD;
 #pragma unroll
-        for (int k = 0; k < D; k++) {
-            double pd = live ? (pol_here * dDn[k] + dp_here[k] * Dn) : 0.0;
-            pd = xwave_sum(pd);
-            if (lane == 0) A.daggpart[pb * (size_t)(XG * DD) + x * D + k] = pd;
+            for (int k = 0; k < D; k++) {
+                const double pd = xwave_reduce63(live ? (pol_here * mx[1 + k] + dp_here[k] * Dn) : 0.0);
+                if (lane == 63) A.daggpart[pb * (size_t)(XG * DD) + x * D + k] = pd;
+            }
         }
         cur = nxt;
         episode++;
         XSTAMP(1, son, t, 5);
-        xbarrier(A.sy, x, episode * (unsigned)Sact, 1, son, t);
+        xbarrier(A.sy, x, cW, Sact, episode, 1, son, t, !runahead);
     }
+    if (runahead && sink_i == 0x7f123457) A.Dvirt[0] = 1.0;     // (practically never true: the touches above must not be optimised away)
+}
+
+// rho_t = 1/(1+r_t) for every period (the X half's discounting; same expression as egm_X)
+__global__ void k_xrho(const double *xhh, int n_hh, int P, double *rho) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P) rho[t] = 1.0 / (1.0 + xhh[n_hh * t]);
 }
 
 // row 0 of every column of D_1..D_P: add the virtual mass the forward sweep kept apart (member order fixed)
