@@ -45,7 +45,9 @@ def ks_setup(n_a, n_e, T):
                     np.array_equal(g["Pi"], m.heterogeneity["productivity"].transition):
                 ss = h.SteadyState({k: float(g[f"var_{k}"]) for k in m.variables}, {"KD": g["policy"]}, None, g["D"], g["value"])
         if ss is None:
-            ss, _ = h.get_SteadyStates(m)
+            # host VFI: the committed goldens were generated without a GPU, and the steady state must be the same
+            # bit for bit here and on the GPU box (the device VFI has its own tests: test_gpu_steady_state.py)
+            ss, _ = h.get_SteadyStates(m, vfi="host")
         wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
         orc = Oracle(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons)
         _SS_CACHE[key] = (m, ss, orc)
