@@ -519,7 +519,7 @@ static int x_run(hank_ctx *ctx, XTan *w) {
         ab.dxr = w ? w->dxr : nullptr; ab.dxw = w ? w->dxw : nullptr; ab.dxt = w ? w->dxt : nullptr;
         ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 * p;
         ab.dpol = w ? w->dpol + ps.dpol_off : nullptr;
-        const size_t lds = sizeof(double) * ((size_t)x_slots(ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e) + 64;
+        const size_t lds = sizeof(double) * ((size_t)x_slots(ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a) + 64;
         if (X.maxt == 768) x_launch<768>(ps.D, true, grd, blk, lds, s, ab, af);
         else x_launch<1024>(ps.D, true, grd, blk, lds, s, ab, af);
         ctx->stats[0]++;

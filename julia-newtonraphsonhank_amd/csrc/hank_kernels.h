@@ -185,10 +185,17 @@ __device__ inline YOut egm_Y(const Consts &c, const KNOTS sc, int a, int e, doub
         bool have = false;    // vlo/vhi hold sc[lo], sc[hi] (bracket found by the first probe)
         double vlo = 0.0, vhi = 0.0;
         if (guess >= 0) {
+            // probe the guessed bracket AND its two neighbours in one round trip (four independent loads): a bracket
+            // that moved by one knot — the common miss — needs no second trip
             const int p = guess < n - 1 ? guess : n - 2;
-            const double sp = sc[p], sp1 = sc[p + 1];
+            const int pm = p > 0 ? p - 1 : 0, pp = p + 2 < n ? p + 2 : n - 1;
+            const double sm = sc[pm], sp = sc[p], sp1 = sc[p + 1], sp2 = sc[pp];
             if (sp <= x && x < sp1) {
-                lo = p; hi = p + 1; have = true; vlo = sp; vhi = sp1;   // the usual case: one round trip
+                lo = p; hi = p + 1; have = true; vlo = sp; vhi = sp1;   // the usual case
+            } else if (p + 2 < n && sp1 <= x && x < sp2) {
+                lo = p + 1; hi = p + 2; have = true; vlo = sp1; vhi = sp2;
+            } else if (p > 0 && sm <= x && x < sp) {
+                lo = p - 1; hi = p; have = true; vlo = sm; vhi = sp;
             } else if (sp1 <= x) {          // gallop up
                 lo = p + 1;
                 for (int step = 1;; step <<= 1) {

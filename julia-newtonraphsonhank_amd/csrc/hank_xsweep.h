@@ -136,6 +136,10 @@ __device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
     return g;
 }
 
+// workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, NOT for its global loads and stores
+// (__syncthreads() carries a fence that drains vmcnt: the dpol stores and the run-ahead touches would stall here)
+__device__ __forceinline__ void xlds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // one episode of the group barrier. No atomics (they execute at the memory side, a fabric round trip each): member c
 // publishes the episode number in ITS word of the group's flag line with a plain store — the line lives in the XCD's
 // L2 like the state itself — and wave 0 of every member polls all members' words with ONE sc1 load per trip.
@@ -144,7 +148,7 @@ __device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
 __device__ __forceinline__ void xbarrier(XSync *sy, int x, int c, int members, unsigned episode, int sw = 0, int son = -1, int sper = -1, bool drain = true) {
     if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave: its stores have reached L2
     XSTAMP(sw, son, sper, 8);
-    __syncthreads();
+    xlds_barrier();
     XSTAMP(sw, son, sper, 9);
     if (threadIdx.x < 64) {
         if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c]) = episode;
@@ -159,14 +163,44 @@ __device__ __forceinline__ void xbarrier(XSync *sy, int x, int c, int members, u
         }
     }
     XSTAMP(sw, son, sper, 10);
-    __syncthreads();
+    xlds_barrier();
     XSTAMP(sw, son, sper, 11);
 }
 
-// knots of one column, read from the L2-resident state
+// knots of one column, read from the L2-resident state. Everything egm_Y is going to look at in the usual case — the
+// row's own knot and its lower neighbour (sortedness check), the column's two end knots (flat extrapolation) and the
+// four knots around the guessed bracket — is fetched in ONE batch of independent loads up front: behind the branches
+// of the bracket search each of them would be a round trip of its own. Anything else (a gallop after a far move) is
+// loaded on demand.
 struct XKnots {
     const double *p;
-    __device__ __forceinline__ double operator[](int i) const { return xld(p + i); }
+    int a, n, i0, i1, i2, i3;
+    double sa, sam1, s0, sN, w0, w1, w2, w3;
+    __device__ __forceinline__ void preload(const double *col, int a_, int n_, int guess) {
+        p = col; a = a_; n = n_;
+        sa = xld(col + a);
+        sam1 = xld(col + (a > 0 ? a - 1 : 0));
+        s0 = xld(col);
+        sN = xld(col + n - 1);
+        i0 = i1 = i2 = i3 = -1;
+        w0 = w1 = w2 = w3 = 0.0;
+        if (guess >= 0) {
+            const int q = guess < n - 1 ? guess : n - 2;
+            i0 = q > 0 ? q - 1 : 0; i1 = q; i2 = q + 1; i3 = q + 2 < n ? q + 2 : n - 1;
+            w0 = xld(col + i0); w1 = xld(col + i1); w2 = xld(col + i2); w3 = xld(col + i3);
+        }
+    }
+    __device__ __forceinline__ double operator[](int i) const {
+        if (i == a) return sa;
+        if (i == a - 1) return sam1;
+        if (i == i1) return w1;
+        if (i == i2) return w2;
+        if (i == i0) return w0;
+        if (i == i3) return w3;
+        if (i == 0) return s0;
+        if (i == n - 1) return sN;
+        return xld(p + i);
+    }
 };
 
 __device__ __forceinline__ double xwave_sum(double v) {            // butterfly: every lane ends with the same sum, fixed order
@@ -246,7 +280,8 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     constexpr int SL = XTile<D>::SL;
     double *Vsh = xl;                                   // [ne][64][SL]
     double *Pish = Vsh + (size_t)SL * ne * 64;          // [ne*ne]
-    int *ctl = reinterpret_cast<int *>(Pish + ne * ne);
+    double *ash = Pish + ne * ne;                       // [na]: the wealth grid (the bracket's grid values are a dependent load)
+    int *ctl = reinterpret_cast<int *>(ash + na);
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
@@ -260,6 +295,9 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     const bool leader = x == 0;
     const size_t pt = (size_t)e * na + (own ? a : 0);
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    for (int k = threadIdx.x; k < na; k += blockDim.x) ash[k] = c.a[k];
+    Consts cl = c;                                      // what egm_Y sees: the same model, grid served from LDS
+    cl.a = ash;
     const double ze = c.z[e], xa = c.a[own ? a : 0];
     // this group's view of the ping-pong state: half h starts h*hs rows further on (no arrays indexed by h: they would
     // live in scratch)
@@ -326,7 +364,8 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
 #pragma unroll
             for (int k = 0; k < DD; k++) dV[k] = 0.0;
             if (own) {
-                const XKnots kn{sS + (size_t)cur * hs + (size_t)e * na};
+                XKnots kn;
+                kn.preload(sS + (size_t)cur * hs + (size_t)e * na, a, na, guess);
                 const size_t rb = (size_t)cur * hs + (size_t)e * na;
                 double d0[DD], d1[DD];
 #pragma unroll
@@ -336,7 +375,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
                     rows.load(rb + pg, d0);
                     rows.load(rb + pg + 1, d1);
                 }
-                const YOut o = egm_Y(c, kn, a, e, r, w, tr, A.err, t, guess);
+                const YOut o = egm_Y(cl, kn, a, e, r, w, tr, A.err, t, guess);
                 XSTAMP(0, son, t, 1);
                 if (D > 0 && o.ib != pg && (o.A != 0.0 || o.B != 0.0)) {
                     rows.load(rb + o.ib, d0);
@@ -369,7 +408,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
                 xtile_store<SL>(myt, vs);
             }
             XSTAMP(0, son, t, 2);
-            __syncthreads();
+            xlds_barrier();
             XSTAMP(0, son, t, 3);
         }
         if (i < P) {
@@ -465,6 +504,8 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
         const size_t hb = (size_t)cur * hs;             // this period reads half `cur`
         const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;      // row index into dpol
         int clo = 0;
+        bool vnz_next = false;                          // some column is clamped this period (every wave reads all n_e counts)
+        for (int k = 0; k < ne; k++) vnz_next = vnz_next || R.clo[(size_t)t * ne + k] > 0;
         double accD = 0.0, acc[DD], polr = 0.0, dpr[DD];
 #pragma unroll
         for (int k = 0; k < DD; k++) acc[k] = dpr[k] = 0.0;
@@ -591,7 +632,8 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
             for (int k = 0; k < D; k++) vs[1 + k] = acc[k];
             xtile_store<SL>(myt, vs);
         }
-        vnz = __syncthreads_or(clo > 0) != 0;
+        xlds_barrier();
+        vnz = vnz_next;
         XSTAMP(1, son, t, 3);
         const int nxt = cur ^ 1;
         if (!runahead) {
