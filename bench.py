@@ -137,11 +137,35 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     el = (time.perf_counter() - t0) / reps
     tm = hb.last_timings()
     G8 = hb.G * 8
-    np_ = tm["dual_backward"]["launches"] if hb.stats()["schedule"] == 1 else 1      # passes of the persistent schedule
-    per = (P * (np_ + Nw)) if hb.stats()["schedule"] == 1 else (tm["dual_backward"]["launches"] * (1 + Nw))
+    if hb.stats()["schedule"] == 1:
+        kb, kf, np_ = "tangent_backward", "tangent_forward", tm["tangent_backward"]["launches"]
+        per = P * Nw
+    else:
+        kb, kf, np_ = "dual_backward", "dual_forward", 1
+        per = tm["dual_backward"]["launches"] * (1 + Nw)
     extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el, "passes": np_,
-                           "backward_sweep_GBs": G8 * per / (1e-3 * tm["dual_backward"]["ms"]) / 1e9,
-                           "forward_sweep_GBs": G8 * per / (1e-3 * tm["dual_forward"]["ms"]) / 1e9}
+                           "backward_sweep_GBs": G8 * per / (1e-3 * tm[kb]["ms"]) / 1e9,
+                           "forward_sweep_GBs": G8 * per / (1e-3 * tm[kf]["ms"]) / 1e9}
+    # the y-iteration's access pattern (NewtonRaphson.jl:91-111): ONE primal, then JVP batches at that record
+    hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
+    Nj = N
+    d_dxj = torch.randn(2 * P * Nj, dtype=torch.float64, device=dev)
+    d_outj = torch.empty(P * Nj, dtype=torch.float64, device=dev)
+    hb.jvp_dev(d_dxj.data_ptr(), Nj, d_outj.data_ptr()); hb.sync()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        hb.jvp_dev(d_dxj.data_ptr(), Nj, d_outj.data_ptr())
+    hb.sync()
+    el = (time.perf_counter() - t0) / reps
+    extra["jvp_at_recorded_primal"] = {"tangents": Nj, "JVPs_per_s": Nj / el, "ms_per_batch": 1e3 * el}
+    d_dx1 = torch.randn(2 * P, dtype=torch.float64, device=dev)
+    hb.jvp_dev(d_dx1.data_ptr(), 1, d_outj.data_ptr()); hb.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        hb.jvp_dev(d_dx1.data_ptr(), 1, d_outj.data_ptr())
+    hb.sync()
+    extra["single_tangent_jvp_ms"] = 1e3 * (time.perf_counter() - t0) / reps
     # configs[1]'s grid with a mild shock and with RunMain.jl's Z_t = 1 + 0.8^t, then the headline grid
     for n_a, n_e, shock in ((500, 4, 0.01), (500, 4, 0.8), (2000, 11, 0.01)):
         try:
@@ -225,7 +249,8 @@ def main():
     hb.check()
     fence()
     t0 = time.perf_counter()
-    split_keys = args.split and hb.stats()["schedule"] == 0     # the persistent schedule runs a dual pass for every entry point
+    # the XCD-local persistent schedule always runs the Float64 sweeps and the tangent sweeps as separate launches
+    split_keys = args.split or hb.stats()["schedule"] == 1
     sweeps = {k: 0.0 for k in (("primal_backward", "primal_forward", "tangent_backward", "tangent_forward") if split_keys
                                else ("dual_backward", "dual_forward"))}
     for _ in range(args.steps):
@@ -256,16 +281,18 @@ def main():
         # dominant kernel: the per-period tangent kernels (k_tan_back / k_tan_fwd). One launch moves
         # the policy partials of ONE period for N directions: G*8*N algorithmic bytes
         # (B_alg = 2*P*G*8*(1+N) per batch = G*8 bytes per (sweep, period, direction)).
-        if split_keys:
+        if schedule == 1:
+            # XCD-local persistent sweeps: ONE launch carries a whole sweep (P periods). The kernels that move the
+            # algorithmic bytes are the tangent sweeps (the policy-partials sequence: written once by k_xtan_back, read
+            # once by k_xtan_fwd): P*G*8*N_pass per launch; a batch wider than 32 runs as ceil(N/32) passes. The Float64
+            # sweeps (k_xsweep_*<0>) move P*G*8 bytes each and are latency-bound: reported beside, not hidden.
+            dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
+            kname = {"tangent_backward": "k_xtan_back", "tangent_forward": "k_xtan_fwd"}[dom]
+            bytes_per_launch = P * G * 8 * N / launches[dom]
+        elif split_keys:
             dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
             kname = {"tangent_backward": "k_tan_back", "tangent_forward": "k_tan_fwd"}[dom]
             bytes_per_launch = G * 8 * N
-        elif schedule == 1:
-            # XCD-local persistent sweeps: ONE launch carries a whole sweep (P periods) of the Float64 recurrence and the
-            # pass's directions: P*G*8*(1+N_pass) algorithmic bytes; a batch wider than 32 runs as ceil(N/32) passes
-            dom = max(("dual_backward", "dual_forward"), key=lambda k: acc[k])
-            kname = {"dual_backward": "k_xsweep_back", "dual_forward": "k_xsweep_fwd"}[dom]
-            bytes_per_launch = P * G * 8 * (launches[dom] + N) / launches[dom]
         else:   # a dual-sweep launch advances the primal and the N tangents by one period: G*8*(1+N)
             dom = max(("dual_backward", "dual_forward"), key=lambda k: acc[k])
             kname = {"dual_backward": "k_fused_back", "dual_forward": "k_fused_fwd"}[dom]

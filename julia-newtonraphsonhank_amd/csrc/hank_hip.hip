@@ -414,7 +414,7 @@ static int x_setup(hank_ctx *ctx) {
     X.maxt = 64 * (c.n_e + 1) <= 768 ? 768 : 1024;
     X.dmax = X.maxt == 768 ? XD_MAX : 2;
     const size_t G = c.G, GV = G + 64 * (size_t)c.n_e, P = c.P;
-    HIPC(ctx, dmalloc(&X.sync, (size_t)2 * XPASS_MAX));
+    HIPC(ctx, dmalloc(&X.sync, (size_t)2 + 2 * XPASS_MAX));
     HIPC(ctx, dmalloc(&X.st_s, 2 * XG * G));
     HIPC(ctx, dmalloc(&X.st_ds, 2 * XG * G * X.dmax));
     HIPC(ctx, dmalloc(&X.st_D, 2 * XG * GV));
@@ -470,98 +470,143 @@ static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
     return HANK_OK;
 }
 
-static int x_slots(int D) { return D == 0 ? 1 : (D == 1 ? 2 : (D == 2 ? 4 : 6)); }     // XTile<D>::SL
 
+// the primal sweeps are the D = 0 instances of the dual kernels (hank_xsweep.h)
 template <int MAXT>
-static void x_launch(int D, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XBackArgs &ab, const XFwdArgs &af) {
+static void x_launch_primal(bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XBackArgs &ab, const XFwdArgs &af) {
+    if (back) hipLaunchKernelGGL((k_xsweep_back<0, MAXT>), grd, blk, lds, s, ab);
+    else hipLaunchKernelGGL((k_xsweep_fwd<0, MAXT>), grd, blk, lds, s, af);
+}
+template <int MAXT>
+static void x_launch_tan(int D, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XTanBackArgs &ab, const XTanFwdArgs &af) {
 #define XL(DV)                                                                                       \
     do {                                                                                             \
-        if (back) hipLaunchKernelGGL((k_xsweep_back<DV, MAXT>), grd, blk, lds, s, ab);               \
-        else hipLaunchKernelGGL((k_xsweep_fwd<DV, MAXT>), grd, blk, lds, s, af);                     \
+        if (back) hipLaunchKernelGGL((k_xtan_back<DV, MAXT>), grd, blk, lds, s, ab);                 \
+        else hipLaunchKernelGGL((k_xtan_fwd<DV, MAXT>), grd, blk, lds, s, af);                       \
     } while (0)
-    if (D == 0) XL(0);
-    else if (D == 1) XL(1);
+    if (D == 1) XL(1);
     else if (D == 2) XL(2);
     else if (D == 4) { if constexpr (MAXT == 768) XL(4); }
 #undef XL
 }
 
-// the whole household block at the context's current x (d_xhh) and boundary: Float64 recurrences (w == nullptr) or
-// value and the N partials of `w` together — two persistent launches per pass (backward, forward)
-static int x_run(hank_ctx *ctx, XTan *w) {
+static int x_serialize_begin(hank_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_xmutex);
+    if (g_xlast[ctx->device & 63]) HIPC(ctx, hipStreamWaitEvent(ctx->stream, g_xlast[ctx->device & 63], 0));
+    return HANK_OK;
+}
+static int x_serialize_end(hank_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_xmutex);
+    hipEvent_t &e = g_xlast[ctx->device & 63];
+    if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPC(ctx, hipEventRecord(e, ctx->stream));
+    return HANK_OK;
+}
+
+// the Float64 recurrences at the context's current x (d_xhh) and boundary: two persistent launches on ONE XCD's
+// workgroups (the policy sequence, the distribution path and the linearisation record the tangent sweeps read)
+static int x_run_primal(hank_ctx *ctx) {
     XWork &X = ctx->xw;
     const Consts &c = ctx->c;
-    const size_t P = c.P, G = c.G;
+    const size_t P = c.P;
     hipStream_t s = ctx->stream;
-    {
-        std::lock_guard<std::mutex> lk(g_xmutex);
-        if (g_xlast[ctx->device & 63]) HIPC(ctx, hipStreamWaitEvent(s, g_xlast[ctx->device & 63], 0));
-    }
-    static const std::vector<XPass> primal_only{XPass{0, 0, 0, 1, 0}};
-    const std::vector<XPass> &passes = w ? w->passes : primal_only;
-    const int np = (int)passes.size();
-    HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync) * 2 * np, s));
+    int rc = x_serialize_begin(ctx);
+    if (rc) return rc;
+    HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync) * 2, s));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
-    const int N = w ? w->N : 0;
-    if (w) hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
-    const dim3 grd(X.grid), blk(64 * c.n_e);
-    const dim3 blkf(64 * (c.n_e + 1) <= X.maxt ? 64 * (c.n_e + 1) : 64 * c.n_e);     // + the run-ahead wave where it fits
-    XBackArgs ab{};
-    ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.Ntot = N > 0 ? N : 1;
-    ab.st_s = X.st_s; ab.st_ds = X.st_ds; ab.pol = ctx->R.pol; ab.err = ctx->d_err; ab.rho = X.rho;
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
+    const dim3 grd(X.grid), blk(64 * c.n_e);
+    const char *ra = getenv("HANK_XRUNAHEAD");      // dev knob: bit 0 tangent backward, bit 1 tangent forward, bit 2 primal forward
+    const int ram = ra ? atoi(ra) : 7;
+    const dim3 blkf(((ram & 4) && 64 * (c.n_e + 1) <= X.maxt) ? 64 * (c.n_e + 1) : 64 * c.n_e);     // + the run-ahead wave where it fits
+    XBackArgs ab{};
+    ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.rho = X.rho; ab.Ntot = 1; ab.n0 = 0; ab.N = 0;
+    ab.sy = X.sync; ab.st_s = X.st_s; ab.st_ds = X.st_ds; ab.pol = ctx->R.pol; ab.dpol = nullptr; ab.groups = 1;
+    ab.err = ctx->d_err; ab.R = ctx->R;
     XFwdArgs af{};
-    af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.st_D = X.st_D; af.st_dD = X.st_dD;
-    af.Dseq = ctx->R.Dseq; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart;
-    HIPC(ctx, hipEventRecord(ctx->ev[8], s));
-    for (int p = 0; p < np; p++) {
-        const XPass &ps = passes[p];
-        ab.dxr = w ? w->dxr : nullptr; ab.dxw = w ? w->dxw : nullptr; ab.dxt = w ? w->dxt : nullptr;
-        ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 * p;
-        ab.dpol = w ? w->dpol + ps.dpol_off : nullptr;
-        const size_t lds = sizeof(double) * ((size_t)x_slots(ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a) + 64;
-        if (X.maxt == 768) x_launch<768>(ps.D, true, grd, blk, lds, s, ab, af);
-        else x_launch<1024>(ps.D, true, grd, blk, lds, s, ab, af);
-        ctx->stats[0]++;
-    }
-    HIPC(ctx, hipEventRecord(ctx->ev[9], s));
+    af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.sy = X.sync + 1; af.st_D = X.st_D; af.st_dD = X.st_dD; af.dpol = nullptr;
+    af.groups = 1; af.N = 0; af.Dseq = ctx->R.Dseq; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart; af.daggpart = nullptr; af.record = 1;
+    const size_t ldsb = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * P) + 64;
+    const size_t ldsf = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * P * c.n_e + 64;
+    HIPC(ctx, hipEventRecord(ctx->ev[0], s));
+    if (X.maxt == 768) x_launch_primal<768>(true, grd, blk, ldsb, s, ab, af);
+    else x_launch_primal<1024>(true, grd, blk, ldsb, s, ab, af);
+    HIPC(ctx, hipEventRecord(ctx->ev[1], s));
     hipLaunchKernelGGL(k_lottery, dim3((unsigned)(P * c.n_e)), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
-    const int nb = X.Sact * c.n_e;
-    HIPC(ctx, hipEventRecord(ctx->ev[11], s));
-    for (int p = 0; p < np; p++) {
-        const XPass &ps = passes[p];
-        af.sy = X.sync + 2 * p + 1; af.groups = ps.groups; af.N = ps.N;
-        af.dpol = w ? w->dpol + ps.dpol_off : nullptr; af.daggpart = w ? w->daggpart : nullptr;
-        const size_t lds = sizeof(double) * ((size_t)x_slots(ps.D) * c.n_e * 64 + (size_t)c.n_e * c.n_e) + 64;
-        if (X.maxt == 768) x_launch<768>(ps.D, false, grd, blkf, lds, s, ab, af);
-        else x_launch<1024>(ps.D, false, grd, blkf, lds, s, ab, af);
-        ctx->stats[0]++;
-        if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[12], s));
-        if (w) {
-            const int W = XG * ps.D;
-            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, W, w->dagg_pass);
-            hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, W, ps.n0, ps.N, w->dagg_cm);
-        }
-    }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, nb, 1, ctx->d_agg);
+    HIPC(ctx, hipEventRecord(ctx->ev[6], s));
+    if (X.maxt == 768) x_launch_primal<768>(false, grd, blkf, ldsf, s, ab, af);
+    else x_launch_primal<1024>(false, grd, blkf, ldsf, s, ab, af);
+    HIPC(ctx, hipEventRecord(ctx->ev[2], s));
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact * c.n_e, 1, ctx->d_agg);
     hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
-    HIPC(ctx, hipEventRecord(ctx->ev[10], s));
     HIPC(ctx, hipGetLastError());
-    {
-        std::lock_guard<std::mutex> lk(g_xmutex);
-        hipEvent_t &e = g_xlast[ctx->device & 63];
-        if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIPC(ctx, hipEventRecord(e, s));
-    }
-    X.last_passes = np;
-    ctx->launches[4] = ctx->launches[5] = np;
-    ctx->ev_valid[4] = ctx->ev_valid[5] = true;
-    ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
+    rc = x_serialize_end(ctx);
+    if (rc) return rc;
+    ctx->stats[0] += 2;
+    X.last_passes = 1;
+    ctx->launches[0] = ctx->launches[1] = 1;
+    ctx->ev_valid[0] = ctx->ev_valid[1] = true;
+    ctx->ev_valid[2] = ctx->ev_valid[3] = ctx->ev_valid[4] = ctx->ev_valid[5] = false;
     ctx->primal_done = true;
     for (XTan &t : X.tans) t.valid = false;
-    if (w) w->valid = true;
+    ctx->xcur = nullptr;
+    return HANK_OK;
+}
+
+// the N partials of `w` at the recorded primal: two persistent launches per pass of up to 8*dmax directions, every XCD a group
+static int x_run_tangent(hank_ctx *ctx, XTan *w) {
+    XWork &X = ctx->xw;
+    const Consts &c = ctx->c;
+    const size_t P = c.P;
+    hipStream_t s = ctx->stream;
+    int rc = x_serialize_begin(ctx);
+    if (rc) return rc;
+    const int np = (int)w->passes.size(), N = w->N;
+    // sync blocks 0, 1 belong to the primal sweeps (their status is checked with this call's when both ran unchecked)
+    HIPC(ctx, hipMemsetAsync(X.sync + 2, 0, sizeof(XSync) * 2 * np, s));
+    hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
+    const dim3 grd(X.grid);
+    const char *ra = getenv("HANK_XRUNAHEAD");      // dev knob: bit 0 tangent backward, bit 1 tangent forward, bit 2 primal forward
+    const int ram = ra ? atoi(ra) : 7;
+    const bool fits = 64 * (c.n_e + 1) <= X.maxt;
+    const dim3 blk(((ram & 1) && fits) ? 64 * (c.n_e + 1) : 64 * c.n_e), blkF(((ram & 2) && fits) ? 64 * (c.n_e + 1) : 64 * c.n_e);
+    XTanBackArgs ab{};
+    ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st_ds = X.st_ds;
+    XTanFwdArgs af{};
+    af.c = c; af.R = ctx->R; af.st_dD = X.st_dD; af.Dvirt = X.Dvirt; af.daggpart = w->daggpart;
+    HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+    for (int p = 0; p < np; p++) {
+        const XPass &ps = w->passes[p];
+        ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
+        const size_t lds = sizeof(double) * ((size_t)ps.D * c.n_e * 64 + (size_t)c.n_e * c.n_e + P + 3 * P * ps.D) + 64;
+        if (X.maxt == 768) x_launch_tan<768>(ps.D, true, grd, blk, lds, s, ab, af);
+        else x_launch_tan<1024>(ps.D, true, grd, blk, lds, s, ab, af);
+    }
+    HIPC(ctx, hipEventRecord(ctx->ev[4], s));
+    HIPC(ctx, hipEventRecord(ctx->ev[7], s));
+    const int nb = X.Sact * c.n_e;
+    for (int p = 0; p < np; p++) {
+        const XPass &ps = w->passes[p];
+        af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.N = ps.N; af.dpol = w->dpol + ps.dpol_off;
+        const size_t lds = sizeof(double) * ((size_t)ps.D * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * P * c.n_e + 64;
+        if (X.maxt == 768) x_launch_tan<768>(ps.D, false, grd, blkF, lds, s, ab, af);
+        else x_launch_tan<1024>(ps.D, false, grd, blkF, lds, s, ab, af);
+        if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
+        const int W = XG * ps.D;
+        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, W, w->dagg_pass);
+        hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, W, ps.n0, ps.N, w->dagg_cm);
+    }
+    HIPC(ctx, hipGetLastError());
+    rc = x_serialize_end(ctx);
+    if (rc) return rc;
+    ctx->stats[0] += 2 * np;
+    X.last_passes = 1 + np;
+    ctx->launches[2] = ctx->launches[3] = np;
+    ctx->ev_valid[2] = ctx->ev_valid[3] = true;
+    ctx->ev_valid[4] = ctx->ev_valid[5] = false;
+    for (XTan &t : X.tans) t.valid = false;
+    w->valid = true;
     ctx->xcur = w;
-    (void)G;
     return HANK_OK;
 }
 
@@ -575,7 +620,7 @@ static int x_status(hank_ctx *ctx) {
         if (h[k].status[0] != 0) {
             ctx->primal_done = false;
             for (XTan &t : X.tans) t.valid = false;
-            return fail(ctx, HANK_ERR_SWEEP, "persistent %s sweep of pass %zu: %s on XCD %u (workgroups per XCD: %u %u %u %u %u %u %u %u)",
+            return fail(ctx, HANK_ERR_SWEEP, "persistent %s sweep %zu (0 = primal, then one per tangent pass): %s on XCD %u (workgroups per XCD: %u %u %u %u %u %u %u %u)",
                         (k & 1) ? "forward" : "backward", k / 2, h[k].status[0] == XERR_PLACEMENT ? "a group is short of members" : "a wait timed out",
                         h[k].status[1], h[k].ticket[0][0], h[k].ticket[1][0], h[k].ticket[2][0], h[k].ticket[3][0], h[k].ticket[4][0],
                         h[k].ticket[5][0], h[k].ticket[6][0], h[k].ticket[7][0]);
@@ -756,13 +801,13 @@ static int x_primal(hank_ctx *ctx, const double *xhh, hipMemcpyKind kind, double
     int rc = x_setup(ctx);
     if (rc) return rc;
     HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * ctx->c.P, kind, ctx->stream));
-    rc = x_run(ctx, nullptr);
+    rc = x_run_primal(ctx);
     if (rc) return rc;
     if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * ctx->c.P, hipMemcpyDeviceToDevice, ctx->stream));
     return HANK_OK;
 }
-// value and N partials in one dual pass; xhh == nullptr keeps the context's current x (hank_jvp: the Dual pass
-// recomputes the Float64 recurrence from the same inputs, bit for bit, like NewtonRaphson.jl:95 does)
+// value and N partials; xhh == nullptr keeps the recorded primal (hank_jvp): the partials are linear recurrences at
+// that record, so a y-iteration pays the Float64 sweeps once (NewtonRaphson.jl:91) and each JVP (:95) only the tangent sweeps
 static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcpyKind kind, int N, double *d_agg_out, double *d_dagg_out) {
     int rc = x_setup(ctx);
     if (rc) return rc;
@@ -770,9 +815,13 @@ static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcp
     rc = x_ensure_tan(ctx, N, &w);
     if (rc) return rc;
     const size_t P = ctx->c.P;
-    if (xhh) HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, kind, ctx->stream));
+    if (xhh) {
+        HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, kind, ctx->stream));
+        rc = x_run_primal(ctx);
+        if (rc) return rc;
+    }
     HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
-    rc = x_run(ctx, w);
+    rc = x_run_tangent(ctx, w);
     if (rc) return rc;
     if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, w->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
@@ -988,7 +1037,6 @@ int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]) {
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     int a[6] = {0, 6, 3, 7, 8, 9}, b[6] = {1, 2, 4, 5, 9, 10};
-    if (ctx->schedule == 1) { a[5] = 11; b[5] = 12; }      // the forward sweep kernels alone (lottery and reductions excluded)
     for (int k = 0; k < 6; k++) {
         out_ms[k] = -1.0;
         if (ctx->ev_valid[k]) {

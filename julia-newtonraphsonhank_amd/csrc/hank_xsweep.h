@@ -102,8 +102,15 @@ __device__ unsigned long long g_xstamps[2][2][XSTAMP_NP][XSTAMP_NS];      // [sw
         if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && threadIdx.x == 0)                 \
             g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memtime();                              \
     } while (0)
+// stamp taken by lane 0 of wave `wave` (arrival of the other waves at a workgroup barrier)
+#define XSTAMPW(sw, on, per, i, wave)                                                                            \
+    do {                                                                                                         \
+        if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (int)threadIdx.x == 64 * (wave))  \
+            g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memtime();                              \
+    } while (0)
 #else
 #define XSTAMP(sw, on, per, i) do {} while (0)
+#define XSTAMPW(sw, on, per, i, wave) do {} while (0)
 #endif
 
 __device__ inline void xfail(XSync *sy, unsigned code, int x) {
@@ -269,6 +276,7 @@ struct XBackArgs {
     double *dpol;               // [P][groups][G][D] of this pass
     int groups;                 // active groups of this pass = max(1, ceil(N / D))
     int *err;                   // device error word of the context (knots / domain)
+    Record R;                   // R.ib != nullptr: group 0 also records the linearisation (s, kc, ib, A, B, u, v) for the tangent sweeps
 };
 
 template <int D, int MAXT>
@@ -281,7 +289,8 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     double *Vsh = xl;                                   // [ne][64][SL]
     double *Pish = Vsh + (size_t)SL * ne * 64;          // [ne*ne]
     double *ash = Pish + ne * ne;                       // [na]: the wealth grid (the bracket's grid values are a dependent load)
-    int *ctl = reinterpret_cast<int *>(ash + na);
+    double *xsh = ash + na;                             // [P][4]: r_t, w_t, tr_t, rho_t — a cold uniform load per period otherwise
+    int *ctl = reinterpret_cast<int *>(xsh + 4 * (size_t)P);
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
@@ -296,6 +305,9 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     const size_t pt = (size_t)e * na + (own ? a : 0);
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     for (int k = threadIdx.x; k < na; k += blockDim.x) ash[k] = c.a[k];
+    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+        xsh[4 * k] = A.xhh[c.n_hh * k]; xsh[4 * k + 1] = A.xhh[c.n_hh * k + 1]; xsh[4 * k + 2] = hh_tr(c, A.xhh, k); xsh[4 * k + 3] = A.rho[k];
+    }
     Consts cl = c;                                      // what egm_Y sees: the same model, grid served from LDS
     cl.a = ash;
     const double ze = c.z[e], xa = c.a[own ? a : 0];
@@ -324,7 +336,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     // X half of period tx from V_{tx+1}, dV_{tx+1} in LDS (KrusellSmith.jl:59-62; same expressions as egm_X): the knots
     // s_tx and their partials -> state[buf]
     auto xhalf = [&](int tx, int buf) {
-        const double w1 = A.xhh[c.n_hh * tx + 1], tr1 = hh_tr(c, A.xhh, tx);
+        const double w1 = xsh[4 * tx + 1], tr1 = xsh[4 * tx + 2];
         if (!own) return;
         double mx[1 + D];                                  // E and dE_k: one pass over the tile
         xtile_mix<SL, 1 + D>(Vsh + (size_t)lane * SL, Pish + e, ne, ne, mx);
@@ -333,10 +345,11 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
         const double ex = -1.0 / c.gamma;
         if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);
         const double cm = pow_crra(bE, ex);
-        const double rho = A.rho[tx];                      // 1/(1+r_tx), once per period (k_xrho), not once per thread
+        const double rho = xsh[4 * tx + 3];                // 1/(1+r_tx), once per period (k_xrho), not once per thread
         const double s1 = rho * ((cm - (w1 * ze + tr1)) + xa);
         const double kc = rho * (c.beta * ex * (cm / bE));
         sS[(size_t)buf * hs + pt] = s1;
+        if (leader && A.R.ib) { A.R.s[(size_t)tx * G + pt] = s1; A.R.kc[(size_t)tx * G + pt] = kc; }
         if (D > 0) {
             double ds[DD];
 #pragma unroll
@@ -359,7 +372,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
             const int t = P - i;
             cur = (i - 1) & 1;
             XSTAMP(0, son, t, 0);
-            const double r = A.xhh[c.n_hh * t], w = A.xhh[c.n_hh * t + 1], tr = hh_tr(c, A.xhh, t);
+            const double r = xsh[4 * t], w = xsh[4 * t + 1], tr = xsh[4 * t + 2];
             double V = 0.0, dV[DD];
 #pragma unroll
             for (int k = 0; k < DD; k++) dV[k] = 0.0;
@@ -383,7 +396,13 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
                 }
                 guess = o.ib;
                 V = o.V;
-                if (leader) A.pol[(size_t)t * G + pt] = o.g;
+                if (leader) {
+                    A.pol[(size_t)t * G + pt] = o.g;
+                    if (A.R.ib) {
+                        const size_t ro = (size_t)t * G + pt;
+                        A.R.ib[ro] = o.ib; A.R.A[ro] = o.A; A.R.B[ro] = o.B; A.R.u[ro] = o.u; A.R.v[ro] = o.v;
+                    }
+                }
                 if (D > 0) {
                     double dg[DD];
 #pragma unroll
@@ -433,6 +452,7 @@ struct XFwdArgs {
     double *Dvirt;              // [P][n_e][64] that virtual mass, per member (added to row 0 by k_xfix_D)
     double *aggpart;            // [P][Sact*n_e]            Float64 aggregate partials (group 0)
     double *daggpart;           // [P][Sact*n_e][XG*D]      partials of the aggregate
+    int record;                 // group 0 also writes R.lwg for the tangent sweeps
 };
 
 template <int D, int MAXT>
@@ -446,7 +466,8 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
     const int GV = G + 64 * ne;
     double *tile = xl;                                  // [ne][64][SL]
     double *Pish = tile + (size_t)SL * ne * 64;
-    int *ctl = reinterpret_cast<int *>(Pish + ne * ne);
+    int *closh = reinterpret_cast<int *>(Pish + ne * ne);      // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
+    int *ctl = closh + (size_t)P * ne;
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
@@ -454,6 +475,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
     const int Sact = (na + XRW - 1) / XRW;
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
+    for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // wave n_e (when the block has one) is the RUN-AHEAD wave: it only touches next period's record and policy-partial
     // lines of this member's rows, so that every compute wave of the XCD finds them in L2 (its loads wait on its own
@@ -505,7 +527,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
         const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;      // row index into dpol
         int clo = 0;
         bool vnz_next = false;                          // some column is clamped this period (every wave reads all n_e counts)
-        for (int k = 0; k < ne; k++) vnz_next = vnz_next || R.clo[(size_t)t * ne + k] > 0;
+        for (int k = 0; k < ne; k++) vnz_next = vnz_next || closh[t * ne + k] > 0;
         double accD = 0.0, acc[DD], polr = 0.0, dpr[DD];
 #pragma unroll
         for (int k = 0; k < DD; k++) acc[k] = dpr[k] = 0.0;
@@ -533,7 +555,7 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
                 }
             }
         } else {
-            clo = min(max(R.clo[(size_t)t * ne + e], 0), na);
+            clo = min(max(closh[t * ne + e], 0), na);
             const double *Dp = sP + hb + (size_t)e * na;
             // the mass that sits on the virtual rows of this column (needed by the targets of source 0 when row 0 is not
             // clamped, and folded into D_{t-1}[0] there): summed by the wave, member order fixed
@@ -549,6 +571,11 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
                 vD = xwave_sum(vD);
 #pragma unroll
                 for (int k = 0; k < D; k++) vT[k] = xwave_sum(vT[k]);
+            }
+            if (own && leader && A.record) {      // what the tangent sweeps read per SOURCE: {w, ig * D_{t-1}} (k_lottery's w and ig)
+                double Dfull = xld(Dp + r);
+                if (r == 0 && clo == 0) Dfull += vD;
+                R.lwg[base + r] = make_double2(R.lw[base + r], R.ig[base + r] * Dfull);
             }
             if (own) {
                 int4 sg = R.seg[base + r];
@@ -675,6 +702,362 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
         xbarrier(A.sy, x, cW, Sact, episode, 1, son, t, !runahead);
     }
     if (runahead && sink_i == 0x7f123457) A.Dvirt[0] = 1.0;     // (practically never true: the touches above must not be optimised away)
+}
+
+// ================================ tangent-only sweeps at a recorded primal ===================================
+// The dual sweeps above cost what the Float64 recurrence costs — and every group repeats it (bracket search, two
+// roots and four divisions per point and period: ~10x the work of one partial). At a FIXED x (the whole y-iteration,
+// NewtonRaphson.jl:91-111; every pass of a wide batch) the primal sweep runs ONCE (the D = 0 instances above, which
+// also record the linearisation) and the partials run as pure linear recurrences: these two kernels. Same groups, same
+// state exchange through the XCD's L2, same barrier; per point and period a few FMAs per direction.
+template <int D> struct XTileT { static constexpr int SL = D; };     // slots of the tangent tile: D (1, 2, 4, 8)
+
+struct XTanBackArgs {
+    Consts c;
+    Record R;                   // s, kc, ib, A, B, u, v of the recorded primal
+    const double *rho;          // [P] 1/(1+r_t)
+    const double *dxr, *dxw, *dxt;
+    int Ntot, n0, N;
+    XSync *sy;
+    double *st_ds;              // [2][XG][G][D]
+    double *dpol;               // [P][groups][G][D]
+    int groups;
+};
+
+template <int D, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
+    constexpr int SL = XTileT<D>::SL;
+    extern __shared__ __attribute__((aligned(16))) double xl[];
+    const Consts &c = A.c;
+    const Record &R = A.R;
+    const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
+    double *tile = xl;                                  // [ne][64][SL]
+    double *Pish = tile + (size_t)SL * ne * 64;
+    double *rhosh = Pish + ne * ne;                     // [P]
+    double *dxsh = rhosh + P;                           // [P][3][D]: this group's dr, dw, dtr (a cold uniform load per period otherwise)
+    int *ctl = reinterpret_cast<int *>(dxsh + (size_t)P * 3 * D);
+    const XGroup g = xgroup_join(A.sy, ctl);
+    if (!g.ok) return;
+    const int x = g.x, cW = g.c;
+    if (x >= A.groups) return;
+    const int Sact = (na + XRW - 1) / XRW;
+    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
+    if (cW >= Sact) return;
+    for (int k = threadIdx.x; k < P; k += blockDim.x) rhosh[k] = A.rho[k];
+    for (int k = threadIdx.x; k < P * D; k += blockDim.x) {
+        const int t_ = k / D, d_ = k - t_ * D;
+        const bool on = x * D + d_ < A.N;
+        const size_t ix = (size_t)t_ * A.Ntot + A.n0 + x * D + d_;
+        dxsh[(t_ * 3 + 0) * D + d_] = on ? A.dxr[ix] : 0.0;
+        dxsh[(t_ * 3 + 1) * D + d_] = on ? A.dxw[ix] : 0.0;
+        dxsh[(t_ * 3 + 2) * D + d_] = (on && c.n_hh > 2) ? A.dxt[ix] : 0.0;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool runahead = wv >= ne;                     // see k_xsweep_fwd: touches next period's record lines
+    const int e = runahead ? 0 : wv;
+    const int r0 = cW * XRW, a = r0 + lane;
+    const bool own = !runahead && lane < XRW && a < na;
+    const size_t pt = (size_t)e * na + (own ? a : 0);
+    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    const double ze = c.z[e], xa = c.a[own ? a : 0];
+    const size_t hs = (size_t)XG * G;
+    double *const sD = A.st_ds + (size_t)x * G * D;
+    XRows<D> rows;
+    rows.init(sD, (hs + G) * D * 8);
+    double *const myt = tile + ((size_t)e * 64 + lane) * SL;
+    {
+        double z[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) z[k] = 0.0;
+        if (!runahead) xtile_store<SL>(myt, z);         // dV_T = 0 (BackwardIteration.jl:85)
+    }
+    __syncthreads();
+    constexpr int NRA = MAXT == 768 ? 11 : 15;
+    int touched[NRA], sink_i = 0;
+#pragma unroll
+    for (int ee = 0; ee < NRA; ee++) touched[ee] = 0;
+    // the record of the period each half is about to use, fetched one trip ahead (its lines were touched by the
+    // run-ahead wave a period earlier)
+    int ibY = 0;
+    double cA = 0.0, cB = 0.0, cu = 0.0, cv = 0.0, ck = 0.0, cs = 0.0;
+    if (own) { ck = R.kc[(size_t)(P - 1) * G + pt]; cs = R.s[(size_t)(P - 1) * G + pt]; }
+    unsigned episode = 0;
+    const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact - 1) ? 1 : -1);
+    (void)son;
+    // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0), one group barrier after every X
+    for (int i = 0; i <= P; i++) {
+        XSTAMP(0, son, P - i, 0);
+        if (runahead) {
+#pragma unroll
+            for (int ee = 0; ee < NRA; ee++) sink_i ^= touched[ee];
+            const int tn = P - 3 - i;                   // one trip AHEAD of the compute waves' own prefetch (Y record of tn+1, X record of tn)
+            if (tn + 1 >= 0) {
+                const int rows_here = min(XRW, na - r0);
+                int off = 0, len = 0;
+                if (lane < 4) { off = lane * 64; len = rows_here * 4; }
+                else if (lane < 52) { off = ((lane - 4) & 7) * 64; len = rows_here * 8; }
+#pragma unroll
+                for (int ee = 0; ee < NRA; ee++) {
+                    if (ee < ne) {
+                        const size_t elY = (size_t)(tn + 1) * G + (size_t)ee * na + r0, elX = (size_t)(tn > 0 ? tn : 0) * G + (size_t)ee * na + r0;
+                        const char *p;
+                        if (lane < 4) p = reinterpret_cast<const char *>(R.ib + elY);
+                        else if (lane < 12) p = reinterpret_cast<const char *>(R.A + elY);
+                        else if (lane < 20) p = reinterpret_cast<const char *>(R.B + elY);
+                        else if (lane < 28) p = reinterpret_cast<const char *>(R.u + elY);
+                        else if (lane < 36) p = reinterpret_cast<const char *>(R.v + elY);
+                        else if (lane < 44) p = reinterpret_cast<const char *>(R.kc + elX);
+                        else p = reinterpret_cast<const char *>(R.s + elX);
+                        if (lane < 52 && off < len) touched[ee] = *reinterpret_cast<const int *>(p + off);
+                    }
+                }
+            }
+        }
+        if (i > 0) {
+            // ---- Y-tangent of period t: dg = A ds[ib] + B ds[ib+1]; dV = u dr + v ((a dr + z dw + dtr) - dg)
+            const int t = P - i, cur = (i - 1) & 1;
+            double dV[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) dV[k] = 0.0;
+            if (own) {
+                double d0[D], d1[D], dg[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) d0[k] = d1[k] = 0.0;
+                if (cA != 0.0 || cB != 0.0) {
+                    const size_t rb = (size_t)cur * hs + (size_t)e * na;
+                    rows.load(rb + ibY, d0);
+                    rows.load(rb + ibY + 1, d1);
+                }
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    const double dr = dxsh[(t * 3 + 0) * D + k], dw = dxsh[(t * 3 + 1) * D + k], dtr = dxsh[(t * 3 + 2) * D + k];
+                    dg[k] = cA * d0[k] + cB * d1[k];
+                    dV[k] = cu * dr + cv * ((xa * dr + (ze * dw + dtr)) - dg[k]);
+                }
+                xstore_row<D>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * D, dg);
+            }
+            XSTAMP(0, son, t, 1);
+            if (!runahead) xtile_store<SL>(myt, dV);
+            XSTAMP(0, son, t, 2);
+            XSTAMPW(0, son, t, 5, ne / 2);
+            XSTAMPW(0, son, t, 6, ne - 1);
+            XSTAMPW(0, son, t, 7, ne);
+            xlds_barrier();
+            XSTAMP(0, son, t, 3);
+        }
+        if (i < P) {
+            // ---- X-tangent of period tx: ds = kc dE - rho ((z dw + dtr) + s dr)
+            const int tx = P - 1 - i;
+            if (own) {
+                const double rho = rhosh[tx];
+                double mx[D], ds[D];
+                xtile_mix<SL, D>(tile + (size_t)lane * SL, Pish + e, ne, ne, mx);
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    const double dr1 = dxsh[(tx * 3 + 0) * D + k], dw1 = dxsh[(tx * 3 + 1) * D + k], dt1 = dxsh[(tx * 3 + 2) * D + k];
+                    ds[k] = ck * mx[k] - rho * ((ze * dw1 + dt1) + cs * dr1);
+                }
+                xstore_row<D>(sD + ((size_t)(i & 1) * hs + pt) * D, ds);
+                // the record the next trip needs: Y of period tx, X of period tx - 1
+                const size_t ro = (size_t)tx * G + pt;
+                ibY = R.ib[ro]; cA = R.A[ro]; cB = R.B[ro]; cu = R.u[ro]; cv = R.v[ro];
+                if (tx > 0) { ck = R.kc[ro - G]; cs = R.s[ro - G]; }
+            }
+            episode++;
+            XSTAMP(0, son, P - i, 4);
+            xbarrier(A.sy, x, cW, Sact, episode, 0, son, P - i, !runahead);
+        }
+    }
+    if (runahead && sink_i == 0x7f123457) A.dpol[0] = 1.0;      // (practically never true: keeps the touches)
+}
+
+struct XTanFwdArgs {
+    Consts c;
+    Record R;                   // pol, seg, clo, lwg, Dseq of the recorded primal
+    XSync *sy;
+    double *st_dD;              // [2][XG][G + 64*n_e][D]
+    const double *dpol;         // [P][groups][G][D]
+    int groups, N;
+    const double *Dvirt;        // [P][n_e][64] the primal's virtual mass
+    double *daggpart;           // [P][Sact*n_e][XG*D]
+};
+
+template <int D, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
+    constexpr int SL = XTileT<D>::SL;
+    extern __shared__ __attribute__((aligned(16))) double xl[];
+    const Consts &c = A.c;
+    const Record &R = A.R;
+    const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
+    const int GV = G + 64 * ne;
+    double *tile = xl;
+    double *Pish = tile + (size_t)SL * ne * 64;
+    int *closh = reinterpret_cast<int *>(Pish + ne * ne);      // [P][ne]
+    int *ctl = closh + (size_t)P * ne;
+    const XGroup g = xgroup_join(A.sy, ctl);
+    if (!g.ok) return;
+    const int x = g.x, cW = g.c;
+    if (x >= A.groups) return;
+    const int Sact = (na + XRW - 1) / XRW;
+    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
+    if (cW >= Sact) return;
+    for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool runahead = wv >= ne;
+    const int e = runahead ? 0 : wv;
+    const int r0 = cW * XRW, r = r0 + lane;
+    const bool own = !runahead && lane < XRW && r < na;
+    const bool virt = !runahead && lane == 63;
+    const size_t pt = (size_t)e * na + (own ? r : 0);
+    const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;
+    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    const size_t hs = (size_t)XG * GV;
+    double *const sT = A.st_dD + (size_t)x * GV * D;
+    XRows<D> rows;
+    rows.init(sT, (hs + GV) * D * 8);
+    double *const myt = tile + ((size_t)e * 64 + lane) * SL;
+    {
+        double z[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) z[k] = 0.0;
+        if (own || virt) xstore_row<D>(sT + slot * D, z);      // the initial distribution carries no partials
+    }
+    unsigned episode = 1;
+    xbarrier(A.sy, x, cW, Sact, episode, 0, -1, -1, !runahead);
+    constexpr int NRA = MAXT == 768 ? 11 : 15;
+    int touched[NRA], touched2[NRA], sink_i = 0;
+#pragma unroll
+    for (int ee = 0; ee < NRA; ee++) touched[ee] = touched2[ee] = 0;
+    int cur = 0;
+    bool vnz = false;
+    for (int t = 0; t < P; t++) {
+        const size_t base = (size_t)t * G + (size_t)e * na;
+        const size_t hb = (size_t)cur * hs;
+        const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;
+        int clo = 0;
+        bool vnz_next = false;
+        for (int k = 0; k < ne; k++) vnz_next = vnz_next || closh[t * ne + k] > 0;
+        double acc[D], polr = 0.0, Dr = 0.0, dpr[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) acc[k] = dpr[k] = 0.0;
+        if (runahead) {
+#pragma unroll
+            for (int ee = 0; ee < NRA; ee++) sink_i ^= touched[ee] ^ touched2[ee];
+            if (t + 1 < P) {
+                const int rows_here = min(XRW, na - r0);
+                int off = 0, len = 0;
+                if (lane < 16) { off = lane * 64; len = rows_here * 16; }
+                else if (lane < 24) { off = (lane - 16) * 64; len = rows_here * 8; }
+                else if (lane < 40) { off = (lane - 24) * 64; len = rows_here * 16; }
+                else if (lane < 48) { off = (lane - 40) * 64; len = rows_here * 8; }
+                const int off2 = lane * 64, len2 = rows_here * 8 * D;
+#pragma unroll
+                for (int ee = 0; ee < NRA; ee++) {
+                    if (ee < ne) {
+                        const size_t el = (size_t)(t + 1) * G + (size_t)ee * na + r0;
+                        const char *p;
+                        if (lane < 16) p = reinterpret_cast<const char *>(R.seg + el);
+                        else if (lane < 24) p = reinterpret_cast<const char *>(R.pol + el);
+                        else if (lane < 40) p = reinterpret_cast<const char *>(R.lwg + el);
+                        else p = reinterpret_cast<const char *>(R.Dseq + el + G);
+                        if (lane < 48 && off < len) touched[ee] = *reinterpret_cast<const int *>(p + off);
+                        const char *q = reinterpret_cast<const char *>(A.dpol + (((size_t)(t + 1) * A.groups + x) * G + (size_t)ee * na + r0) * D);
+                        if (off2 < len2) touched2[ee] = *reinterpret_cast<const int *>(q + off2);
+                    }
+                }
+            }
+        } else {
+            clo = min(max(closh[t * ne + e], 0), na);
+            double vT[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) vT[k] = 0.0;
+            if (vnz && clo == 0) {           // the partials sitting on this column's virtual rows follow source 0's lottery
+                if (lane < Sact) rows.load(hb + (size_t)G + (size_t)e * 64 + lane, vT);
+#pragma unroll
+                for (int k = 0; k < D; k++) vT[k] = xwave_sum(vT[k]);
+            }
+            if (own) {
+                int4 sg = R.seg[base + r];
+                sg.x = max(sg.x, 0); sg.z = min(sg.z, na);
+                polr = R.pol[base + r];
+                Dr = R.Dseq[base + G + r];                       // D_t[r] (the real row: row 0's virtual mass sits on the virtual lanes)
+                xload_row_plain<D>(A.dpol + (dbase + r) * D, dpr);
+                for (int j0 = sg.x; j0 < sg.z; j0 += 2) {
+                    double2 wg[2];
+                    double dDj[2][D], dpj[2][D];
+                    bool on[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int j = j0 + u;
+                        on[u] = j < sg.z;
+                        wg[u] = make_double2(0.0, 0.0);
+#pragma unroll
+                        for (int k = 0; k < D; k++) dDj[u][k] = dpj[u][k] = 0.0;
+                        if (on[u]) {
+                            wg[u] = R.lwg[base + j];
+                            rows.load(hb + (size_t)e * na + j, dDj[u]);
+                            xload_row_plain<D>(A.dpol + (dbase + j) * D, dpj[u]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int j = j0 + u;
+                        if (!on[u]) continue;
+                        const bool first = j < sg.y;
+                        if (j == 0) {
+#pragma unroll
+                            for (int k = 0; k < D; k++) dDj[u][k] += vT[k];
+                        }
+                        const double wt = first ? wg[u].x : 1.0 - wg[u].x;
+#pragma unroll
+                        for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[u][k] + wg[u].y * dpj[u][k]) : (wt * dDj[u][k] - wg[u].y * dpj[u][k]);
+                    }
+                }
+            }
+            {   // the mass point (see k_xsweep_fwd)
+                double cT[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) cT[k] = 0.0;
+                if (own && r < clo) rows.load(hb + (size_t)e * na + r, cT);
+                if (virt && clo > 0 && vnz) rows.load(hb + slot, cT);
+                if (clo > r0) {
+#pragma unroll
+                    for (int k = 0; k < D; k++) cT[k] = xwave_reduce63(cT[k]);
+                }
+                if (virt) {
+#pragma unroll
+                    for (int k = 0; k < D; k++) acc[k] = cT[k];
+                }
+            }
+            xtile_store<SL>(myt, acc);
+        }
+        xlds_barrier();
+        vnz = vnz_next;
+        const int nxt = cur ^ 1;
+        if (!runahead) {
+            double mx[D];
+            xtile_mix<SL, D>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
+            if (own || virt) xstore_row<D>(sT + ((size_t)nxt * hs + slot) * D, mx);
+            double pol_here = polr, D_here = Dr, dp_here[D];
+#pragma unroll
+            for (int k = 0; k < D; k++) dp_here[k] = dpr[k];
+            if (virt) {          // a virtual row carries row 0's policy; its share of D_t[0] is already in the recorded D_t[0]
+                pol_here = R.pol[base];
+                D_here = 0.0;
+            }
+            const bool live = own || virt;
+            const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const double pd = xwave_reduce63(live ? (pol_here * mx[k] + dp_here[k] * D_here) : 0.0);
+                if (lane == 63) A.daggpart[pb * (size_t)(XG * D) + x * D + k] = pd;
+            }
+        }
+        cur = nxt;
+        episode++;
+        xbarrier(A.sy, x, cW, Sact, episode, 1, -1, -1, !runahead);
+    }
+    if (runahead && sink_i == 0x7f123457) A.daggpart[0] = 1.0;
 }
 
 // rho_t = 1/(1+r_t) for every period (the X half's discounting; same expression as egm_X)

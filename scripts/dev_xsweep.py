@@ -55,13 +55,13 @@ def parity(n_a, n_e, T, N, shock=0.05, pols=True):
     print(f"   xcd vs launch: agg {np.max(np.abs(out['xcd'][0] - out['launch'][0])):.2e} dagg {np.max(np.abs(out['xcd'][1] - out['launch'][1])) / np.abs(out['launch'][1]).max():.2e}", flush=True)
 
 
-def timing(n_a, n_e, T, Ns):
+def timing(n_a, n_e, T, Ns, scheds=("xcd", "launch")):
     m, ss, _ = ks_setup(n_a, n_e, T)
     P = T - 1
     x, Z = ks_paths(m, ss, "x1", 0.01)
     dev = torch.device("cuda", 0)
     d_x = torch.from_numpy(np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()).to(dev)
-    for sched in ("xcd", "launch"):
+    for sched in scheds:
         hb = block(m, sched)
         hb.set_boundary(ss.value, ss.D)
         for N in Ns:
@@ -77,8 +77,14 @@ def timing(n_a, n_e, T, Ns):
             hb.sync()
             el = (time.perf_counter() - t0) / reps
             tm = hb.last_timings()
-            print(f"{sched:6s} {n_a}x{n_e} T={T} N={N:4d}: {1e3 * el:8.3f} ms/step  {N / el:9.0f} JVPs/s   back {tm['dual_backward']['ms']:.3f} fwd {tm['dual_forward']['ms']:.3f} ms "
-                  f"({tm['dual_backward']['launches']} launches)", flush=True)
+            ms = " ".join(f"{k[:1]}{k.split('_')[1][:1]} {v['ms']:.3f}" for k, v in tm.items() if v["ms"] >= 0)
+            hb.check()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                hb.jvp_dev(d_dx.data_ptr(), N, d_out.data_ptr())
+            hb.sync()
+            elj = (time.perf_counter() - t0) / reps
+            print(f"{sched:6s} {n_a}x{n_e} T={T} N={N:4d}: {1e3 * el:8.3f} ms/step  {N / el:9.0f} JVPs/s  | jvp only {1e3 * elj:7.3f} ms {N / elj:9.0f} JVPs/s | {ms}", flush=True)
             hb.check()
         # primal only
         d_agg = torch.empty(P, dtype=torch.float64, device=dev)
@@ -101,6 +107,11 @@ if __name__ == "__main__":
         parity(40, 16, 8, 6)
         parity(37, 3, 9, 70, pols=False)
         parity(2000, 11, 300, 32, shock=0.01, pols=False)
+    if what == "ra":      # run-ahead wave on/off per kernel (HANK_XRUNAHEAD bits: 1 tangent backward, 2 tangent forward, 4 primal forward)
+        for mask in (0, 1, 2, 4, 7):
+            os.environ["HANK_XRUNAHEAD"] = str(mask)
+            print("HANK_XRUNAHEAD =", mask, flush=True)
+            timing(2000, 11, 300, [1, 32], scheds=("xcd",))
     if what in ("all", "time"):
         timing(2000, 11, 300, [1, 8, 16, 32, 64, 128, 256])
         timing(500, 4, 300, [1, 32])
