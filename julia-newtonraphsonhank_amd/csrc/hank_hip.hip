@@ -50,6 +50,8 @@ struct TanWork {
     hipGraphExec_t g_back = nullptr, g_fwd = nullptr;
     hipGraphExec_t g_fback = nullptr, g_ffwd = nullptr;   // dual-sweep graphs (primal + tangents in one chain)
     bool valid = false;  // dpol holds the partials of the current primal
+    int VB = 1, VF = 1, RGB = 1, RGF = 1;   // lane widths and row groups the graphs are captured with
+    unsigned nbf = 0;
 };
 
 
@@ -99,8 +101,13 @@ struct hank_ctx {
     hipEvent_t ev[16] = {};
     bool ev_valid[6] = {false, false, false, false, false, false};
     int launches[6] = {0, 0, 0, 0, 0, 0};
-    TanWork tw;
-    int schedule = 1;              // 1 = XCD-local persistent sweeps (default where supported), 0 = one launch per period
+    std::list<TanWork> tws;        // per batch width, most recently used first (a small cache: Jacobian assembly and Newton alternate widths)
+    TanWork *tw = nullptr;         // the current one
+    // 0 = one launch per period for everything; 1 = XCD-local persistent sweeps for everything; 2 = auto (default where
+    // the persistent sweeps are supported): each entry point takes the faster of the two for its shape — see sched_*
+    int schedule = 2;
+    int last_tan = 0;              // which implementation ran the last tangent sweep (0 launches, 1 persistent): hank_get_dpolicy_seq
+    int xjvp_max = 16;             // auto: batches up to this width take the persistent tangent sweeps
     XWork xw;
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // see hank_stats
@@ -212,8 +219,12 @@ static int build_primal_graphs(hank_ctx *ctx) {
         }                                                                                       \
     } while (0)
 
+// captures ONE pair of tangent graphs, on first use: which = 0 the tangent-only sweeps (hank_jvp), 1 the dual-sweep
+// launches (hank_primal_jvp)
 template <typename VT, typename VF>
-static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, unsigned nbf) {
+static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int which) {
+    const int RGB = w.RGB, RGF = w.RGF;
+    const unsigned nbf = w.nbf;
     const Consts &c = ctx->c;
     const size_t P = c.P;
     const int N = w.N;
@@ -228,18 +239,20 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
     VT *dpol = reinterpret_cast<VT *>(w.dpol);
     VF *dpolf = reinterpret_cast<VF *>(w.dpol), *aggpart = reinterpret_cast<VF *>(w.aggpart);
     const unsigned nbt = (w.nbx + RGB - 1) / RGB;
+    int rc = HANK_OK, cur = 0;
+    if (which == 0) {
     // backward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     hipLaunchKernelGGL(k_tan_in, dim3((PN + 255) / 256), dim3(256), 0, s, w.dxhh, c.n_hh, (int)P, N, w.dxr, w.dxw, w.dxt);
     LAUNCH_RG(RGB, k_tan_back, VT, dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, dxt, w.g, (int)P - 1, 1,
                        ds[1], ds[0], dpol);
-    int cur = 0;
+    cur = 0;
     for (int t = (int)P - 1; t >= 0; t--) {
         LAUNCH_RG(RGB, k_tan_back, VT, dim3(nbt, ny), blk, 0, s, c, ctx->R, ctx->d_xhh, dxr, dxw, dxt, w.g, t, 0,
                            ds[cur], ds[cur ^ 1], dpol);
         cur ^= 1;
     }
-    int rc = end_capture(ctx, &w.g_back);
+    rc = end_capture(ctx, &w.g_back);
     if (rc) return rc;
     // forward tangent sweep
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -255,6 +268,8 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
     if (rc) return rc;
     ctx->launches[2] = (int)P + 2;
     ctx->launches[3] = (int)P + 3;
+    return HANK_OK;
+    }
 
     // ---- dual-sweep graphs: the primal recurrence and the tangent recurrence advance in the SAME
     // chain of launches, the tangent one period behind (it reads the record the previous launch wrote):
@@ -300,13 +315,19 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int RGB, int RGF, u
 }
 
 static int ensure_tanwork(hank_ctx *ctx, int N) {
-    TanWork &w = ctx->tw;
-    if (w.N == N && w.g_back) return HANK_OK;
-    if (w.N) {      // the async entries may still have the old graphs in flight
+    for (auto it = ctx->tws.begin(); it != ctx->tws.end(); ++it)
+        if (it->N == N) { ctx->tws.splice(ctx->tws.begin(), ctx->tws, it); ctx->tw = &ctx->tws.front(); return HANK_OK; }
+    const char *ce = getenv("HANK_TAN_CACHE");
+    const size_t keep = ce ? (size_t)atoi(ce) : 3;
+    while (ctx->tws.size() >= (keep ? keep : 1)) {     // evict the least recently used — the async entries may still have its graphs in flight
         HIPC(ctx, join_side(ctx));
         HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        free_tanwork(ctx->tws.back());
+        ctx->tws.pop_back();
     }
-    free_tanwork(w);
+    ctx->tws.emplace_front();
+    ctx->tw = &ctx->tws.front();
+    TanWork &w = *ctx->tw;
     ctx->stats[1]++;
     const Consts &c = ctx->c;
     const size_t P = c.P, G = c.G;
@@ -343,8 +364,15 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
     HIPC(ctx, dmalloc(&w.dagg, P * N));
     HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
-    if (VB == 2) return VF == 2 ? capture_tangent_graphs<double2, double2>(ctx, w, RGB, RGF, nbf) : capture_tangent_graphs<double2, double>(ctx, w, RGB, RGF, nbf);
-    return VF == 2 ? capture_tangent_graphs<double, double2>(ctx, w, RGB, RGF, nbf) : capture_tangent_graphs<double, double>(ctx, w, RGB, RGF, nbf);
+    w.VB = VB; w.VF = VF; w.RGB = RGB; w.RGF = RGF; w.nbf = nbf;
+    return HANK_OK;
+}
+
+// the graph pair of one schedule, captured the first time that schedule runs at this batch width
+static int ensure_graphs(hank_ctx *ctx, TanWork &w, int which) {
+    if (which == 0 ? w.g_back != nullptr : w.g_fback != nullptr) return HANK_OK;
+    if (w.VB == 2) return w.VF == 2 ? capture_tangent_graphs<double2, double2>(ctx, w, which) : capture_tangent_graphs<double2, double>(ctx, w, which);
+    return w.VF == 2 ? capture_tangent_graphs<double, double2>(ctx, w, which) : capture_tangent_graphs<double, double>(ctx, w, which);
 }
 
 static int x_status(hank_ctx *ctx);
@@ -353,7 +381,7 @@ static int fetch_device_error(hank_ctx *ctx) {
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e[0] == 0) return ctx->schedule == 1 ? x_status(ctx) : HANK_OK;
+    if (e[0] == 0) return ctx->schedule >= 1 ? x_status(ctx) : HANK_OK;
     ctx->primal_done = false;
     switch (e[0]) {
     case ERR_KNOTS:
@@ -517,7 +545,7 @@ static int x_run_primal(hank_ctx *ctx) {
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
     const dim3 grd(X.grid), blk(64 * c.n_e);
     const char *ra = getenv("HANK_XRUNAHEAD");      // dev knob: bit 0 tangent backward, bit 1 tangent forward, bit 2 primal forward
-    const int ram = ra ? atoi(ra) : 7;
+    const int ram = ra ? atoi(ra) : 0;      // measured: the extra wave is the straggler of every workgroup barrier
     const dim3 blkf(((ram & 4) && 64 * (c.n_e + 1) <= X.maxt) ? 64 * (c.n_e + 1) : 64 * c.n_e);     // + the run-ahead wave where it fits
     XBackArgs ab{};
     ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.rho = X.rho; ab.Ntot = 1; ab.n0 = 0; ab.N = 0;
@@ -565,9 +593,10 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     // sync blocks 0, 1 belong to the primal sweeps (their status is checked with this call's when both ran unchecked)
     HIPC(ctx, hipMemsetAsync(X.sync + 2, 0, sizeof(XSync) * 2 * np, s));
     hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
+    hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);     // (the primal may have been recorded by the launches)
     const dim3 grd(X.grid);
     const char *ra = getenv("HANK_XRUNAHEAD");      // dev knob: bit 0 tangent backward, bit 1 tangent forward, bit 2 primal forward
-    const int ram = ra ? atoi(ra) : 7;
+    const int ram = ra ? atoi(ra) : 0;
     const bool fits = 64 * (c.n_e + 1) <= X.maxt;
     const dim3 blk(((ram & 1) && fits) ? 64 * (c.n_e + 1) : 64 * c.n_e), blkF(((ram & 2) && fits) ? 64 * (c.n_e + 1) : 64 * c.n_e);
     XTanBackArgs ab{};
@@ -607,6 +636,8 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     for (XTan &t : X.tans) t.valid = false;
     w->valid = true;
     ctx->xcur = w;
+    ctx->last_tan = 1;
+    for (TanWork &t : ctx->tws) t.valid = false;
     return HANK_OK;
 }
 
@@ -700,14 +731,19 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, dmalloc(&ctx->d_err, 4));
     HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
     HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_stream, hipEventDisableTiming));
-    // schedule: XCD-local persistent sweeps wherever the grid fits one workgroup row-slab per CU of an XCD; the
-    // per-period launches otherwise (and as the fall-back when a sweep cannot form its groups). HANK_SCHEDULE=launch|xcd
-    // forces one (dev knob / A-B).
+    // schedule (measured on MI355X): "auto" wherever the grid fits one 63-row slab per CU of an XCD —
+    // the Float64 sweeps alone (hank_primal) and narrow tangent batches at a recorded primal (hank_jvp, N <= 16) run as
+    // XCD-local persistent sweeps, the dual pass (hank_primal_jvp) and wide batches as per-period launches; both
+    // read and write the same record. HANK_SCHEDULE=launch|xcd forces one implementation for everything (A-B, tests).
     const char *se = getenv("HANK_SCHEDULE");
-    ctx->schedule = x_supported(ctx, prop.multiProcessorCount) ? 1 : 0;
+    ctx->schedule = x_supported(ctx, prop.multiProcessorCount) ? 2 : 0;
     if (se && strcmp(se, "launch") == 0) ctx->schedule = 0;
-    if (se && strcmp(se, "xcd") == 0 && ctx->schedule == 0)
-        return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=xcd: n_a=%d needs %d workgroups per XCD, the device has %d", c.n_a, (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG);
+    if (se && strcmp(se, "xcd") == 0) {
+        if (ctx->schedule == 0)
+            return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=xcd: n_a=%d needs %d workgroups per XCD, the device has %d", c.n_a, (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG);
+        ctx->schedule = 1;
+    }
+    if (const char *xm = getenv("HANK_XJVP_MAX")) ctx->xjvp_max = atoi(xm);
     int rc = HANK_OK;
     if (ctx->schedule == 0) rc = build_primal_graphs(ctx);
     else rc = x_setup(ctx);
@@ -720,7 +756,9 @@ int hank_destroy(hank_ctx *ctx) {
     if (!ctx) return HANK_OK;
     if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-    free_tanwork(ctx->tw);
+    for (TanWork &t : ctx->tws) free_tanwork(t);
+    ctx->tws.clear();
+    ctx->tw = nullptr;
     x_free(ctx);
     if (ctx->ev_stream) (void)hipEventDestroy(ctx->ev_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -768,7 +806,7 @@ int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *s
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     ctx->boundary_set = true;
     ctx->primal_done = false;
-    ctx->tw.valid = false;
+    for (TanWork &t : ctx->tws) t.valid = false;
     ctx->errmsg[0] = 0;
     return HANK_OK;
 }
@@ -792,7 +830,7 @@ static int run_primal(hank_ctx *ctx, double *d_agg_out) {
     ctx->ev_valid[0] = ctx->ev_valid[1] = true;
     ctx->ev_valid[4] = ctx->ev_valid[5] = false;
     ctx->primal_done = true;
-    ctx->tw.valid = false;
+    for (TanWork &t : ctx->tws) t.valid = false;
     return HANK_OK;
 }
 
@@ -827,6 +865,10 @@ static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcp
     if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, w->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
     return HANK_OK;
 }
+static bool use_x_primal(const hank_ctx *ctx) { return ctx->schedule >= 1; }
+static bool use_x_jvp(const hank_ctx *ctx, int N) { return ctx->schedule == 1 || (ctx->schedule == 2 && N <= ctx->xjvp_max); }
+static bool use_x_fused(const hank_ctx *ctx) { return ctx->schedule == 1; }      // auto: the dual-sweep launches hide the primal chain
+
 // a sweep could not form its groups (or timed out): this context continues on the per-period launches
 static int to_launch_schedule(hank_ctx *ctx) {
     ctx->schedule = 0;
@@ -843,7 +885,7 @@ static bool x_fallback_allowed() {
 int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
     if (!ctx || !d_xhh) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
-    if (ctx->schedule == 1) return x_primal(ctx, d_xhh, hipMemcpyDeviceToDevice, d_agg_out);
+    if (use_x_primal(ctx)) return x_primal(ctx, d_xhh, hipMemcpyDeviceToDevice, d_agg_out);
     const size_t P = ctx->c.P;
     HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyDeviceToDevice, ctx->stream));
     return run_primal(ctx, d_agg_out);
@@ -861,15 +903,17 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
     for (size_t t = 0; t < P; t++)
         if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
     int rc = HANK_OK;
-    if (ctx->schedule == 1) {
+    bool done = false;
+    if (use_x_primal(ctx)) {
         rc = x_primal(ctx, xhh, hipMemcpyHostToDevice, nullptr);
         if (rc) return rc;
         rc = fetch_device_error(ctx);
         if (rc == HANK_ERR_SWEEP && x_fallback_allowed()) rc = to_launch_schedule(ctx);
         else if (rc) return rc;
+        else done = true;
         if (rc) return rc;
     }
-    if (ctx->schedule == 0) {
+    if (!done) {
         HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyHostToDevice, ctx->stream));
         rc = run_primal(ctx, nullptr);
         if (rc) return rc;
@@ -885,7 +929,10 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
 }
 
 static int run_jvp(hank_ctx *ctx) {
-    TanWork &w = ctx->tw;
+    TanWork &w = *ctx->tw;
+    int grc = ensure_graphs(ctx, w, 0);
+    if (grc) return grc;
+    ctx->launches[2] = ctx->c.P + 2; ctx->launches[3] = ctx->c.P + 3;
     HIPC(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     HIPC(ctx, hipGraphLaunch(w.g_back, ctx->stream));
     HIPC(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
@@ -894,21 +941,24 @@ static int run_jvp(hank_ctx *ctx) {
     HIPC(ctx, hipGraphLaunch(w.g_fwd, ctx->stream));
     HIPC(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->ev_valid[2] = ctx->ev_valid[3] = true;
+    for (TanWork &t : ctx->tws) t.valid = false;
     w.valid = true;
+    ctx->last_tan = 0;
+    for (XTan &t : ctx->xw.tans) t.valid = false;
     return HANK_OK;
 }
 
 int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_out) {
     if (!ctx || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
-    if (ctx->schedule == 1) return x_dual(ctx, nullptr, d_dxhh, hipMemcpyDeviceToDevice, N, nullptr, d_dagg_out);
+    if (use_x_jvp(ctx, N)) return x_dual(ctx, nullptr, d_dxhh, hipMemcpyDeviceToDevice, N, nullptr, d_dagg_out);
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
     const size_t P = ctx->c.P;
-    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, d_dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw->dxhh, d_dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyDeviceToDevice, ctx->stream));
     rc = run_jvp(ctx);
     if (rc) return rc;
-    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, ctx->tw->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
     return HANK_OK;
 }
 
@@ -917,19 +967,20 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
     const size_t P = ctx->c.P;
     int rc = HANK_OK;
-    if (ctx->schedule == 1) {
+    if (use_x_jvp(ctx, N)) {
         rc = x_dual(ctx, nullptr, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
         if (rc) return rc;
         rc = fetch_device_error(ctx);
-        if (rc == HANK_ERR_SWEEP && x_fallback_allowed()) {
+        const bool fell_back = rc == HANK_ERR_SWEEP && x_fallback_allowed();
+        if (fell_back) {
             rc = to_launch_schedule(ctx);
             if (rc) return rc;
-            rc = run_primal(ctx, nullptr);       // the launch schedule needs its own record of the primal at the current x
+            rc = run_primal(ctx, nullptr);       // re-record the primal at the current x with the launches
             if (rc) return rc;
             rc = fetch_device_error(ctx);
         }
         if (rc) return rc;
-        if (ctx->schedule == 1) {
+        if (!fell_back) {
             HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->xcur->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
             HIPC(ctx, hipStreamSynchronize(ctx->stream));
             ctx->errmsg[0] = 0;
@@ -938,17 +989,20 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
     }
     rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
-    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
     rc = run_jvp(ctx);
     if (rc) return rc;
-    HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->tw->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     ctx->errmsg[0] = 0;
     return HANK_OK;
 }
 
 static int run_fused(hank_ctx *ctx) {
-    TanWork &w = ctx->tw;
+    TanWork &w = *ctx->tw;
+    int grc = ensure_graphs(ctx, w, 1);
+    if (grc) return grc;
+    ctx->launches[4] = ctx->launches[5] = ctx->c.P + 5;
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
     HIPC(ctx, hipGraphLaunch(w.g_fback, ctx->stream));
@@ -958,7 +1012,10 @@ static int run_fused(hank_ctx *ctx) {
     ctx->ev_valid[4] = ctx->ev_valid[5] = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
     ctx->primal_done = true;
+    for (TanWork &t : ctx->tws) t.valid = false;
     w.valid = true;
+    ctx->last_tan = 0;
+    for (XTan &t : ctx->xw.tans) t.valid = false;
     return HANK_OK;
 }
 
@@ -966,17 +1023,17 @@ int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh
                         double *d_dagg_out) {
     if (!ctx || !d_xhh || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
-    if (ctx->schedule == 1) return x_dual(ctx, d_xhh, d_dxhh, hipMemcpyDeviceToDevice, N, d_agg_out, d_dagg_out);
+    if (use_x_fused(ctx)) return x_dual(ctx, d_xhh, d_dxhh, hipMemcpyDeviceToDevice, N, d_agg_out, d_dagg_out);
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
     const size_t P = ctx->c.P;
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, d_dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->tw->dxhh, d_dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyDeviceToDevice, ctx->stream));
     rc = run_fused(ctx);
     if (rc) return rc;
     if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
-    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, ctx->tw.dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, ctx->tw->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
     return HANK_OK;
 }
 
@@ -988,26 +1045,26 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
         if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
     int rc = HANK_OK;
     const double *d_dagg = nullptr;
-    if (ctx->schedule == 1) {
+    if (use_x_fused(ctx)) {
         rc = x_dual(ctx, xhh, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
         if (rc) return rc;
         rc = fetch_device_error(ctx);
         if (rc == HANK_ERR_SWEEP && x_fallback_allowed()) rc = to_launch_schedule(ctx);
         else if (rc) return rc;
+        else d_dagg = ctx->xcur->dagg_cm;
         if (rc) return rc;
-        if (ctx->schedule == 1) d_dagg = ctx->xcur->dagg_cm;
     }
-    if (ctx->schedule == 0) {
+    if (!d_dagg) {
         rc = ensure_tanwork(ctx, N);
         if (rc) return rc;
         HIPC(ctx, join_side(ctx));
         HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyHostToDevice, ctx->stream));
-        HIPC(ctx, hipMemcpyAsync(ctx->tw.dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
+        HIPC(ctx, hipMemcpyAsync(ctx->tw->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, hipMemcpyHostToDevice, ctx->stream));
         rc = run_fused(ctx);
         if (rc) return rc;
         rc = fetch_device_error(ctx);
-        if (rc) { ctx->tw.valid = false; return rc; }
-        d_dagg = ctx->tw.dagg_cm;
+        if (rc) { ctx->tw->valid = false; return rc; }
+        d_dagg = ctx->tw->dagg_cm;
     }
     if (agg_out) HIPC(ctx, hipMemcpyAsync(agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipMemcpyAsync(dagg_out, d_dagg, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
@@ -1071,7 +1128,7 @@ int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
     const size_t total = (size_t)ctx->c.P * ctx->c.G * N;
     double *tmp = nullptr;
-    if (ctx->schedule == 1) {
+    if (ctx->last_tan == 1) {
         XTan *x = ctx->xcur;
         if (!x || !x->valid || x->N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
         HIPC(ctx, dmalloc(&tmp, total));
@@ -1087,8 +1144,8 @@ int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
         HIPC(ctx, e2);
         return HANK_OK;
     }
-    TanWork &w = ctx->tw;
-    if (!w.valid || w.N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
+    if (!ctx->tw || !ctx->tw->valid || ctx->tw->N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
+    TanWork &w = *ctx->tw;
     HIPC(ctx, dmalloc(&tmp, total));
     hipLaunchKernelGGL(k_export_dpol, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w.dpol, ctx->c.G, ctx->c.P, N, tmp);
     hipError_t e1 = hipMemcpyAsync(out, tmp, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream);

@@ -78,6 +78,21 @@ __device__ inline double block_sum(double x, double *red, int nthreads) {
     return r;
 }
 
+// Workgroup barrier for LDS hand-offs: waits for this wave's LDS operations only. __syncthreads() carries a fence that
+// also drains vmcnt — every write-through (sc1) store issued before it would have to reach memory before the barrier
+// opens, although nothing behind these barriers reads global memory another thread of the block wrote (dev knob
+// HANK_RAW_BARRIER=0 restores __syncthreads()).
+#ifndef HANK_RAW_BARRIER
+#define HANK_RAW_BARRIER 1
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if HANK_RAW_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // dev knob: how the big streaming stores leave the CU (0 plain, 1 sc1 write-through, 2 nontemporal)
 #ifndef HANK_ST_DPOL
 #define HANK_ST_DPOL 1
@@ -295,7 +310,7 @@ __device__ inline void egm_step_body(const Consts &c, const Record &R, const dou
         st_mode<HANK_ST_REC>(&R.B[off], o.B); st_mode<HANK_ST_REC>(&R.u[off], o.u); st_mode<HANK_ST_REC>(&R.v[off], o.v);
         Vsh[e * RBP + row] = o.V;
     }
-    __syncthreads();
+    lds_barrier();
     if (t > 0 && a < c.n_a) {
         const double r1 = xhh[c.n_hh * (t - 1)], w1 = xhh[c.n_hh * (t - 1) + 1], tr1 = hh_tr(c, xhh, t - 1);
         const size_t off1 = base - c.G + (size_t)e * c.n_a + a;
@@ -398,7 +413,7 @@ __device__ inline void dist_step_body(const Consts &c, const Record &R, int t, d
         if (row == 0) acc += part;
     }
     if (r < n) Dsh[e * RBP + row] = acc;
-    __syncthreads();
+    lds_barrier();
     double part = 0.0;
     if (r < n) {
         const int e2 = e;  // D_new[r,e2] = sum_e D_mid[r,e] * Pi[e,e2]
@@ -621,7 +636,7 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
         }
         dVsh[q][e * 64 + lane] = dV;
     }
-    __syncthreads();
+    lds_barrier();
     if (tx < 0) return;
 #pragma unroll
     for (int q = 0; q < RG; q++) {
@@ -863,7 +878,7 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
 #pragma unroll
         for (int q = 0; q < RG; q++) sh[q][e * 64 + lane] = acc[q];
     }
-    __syncthreads();
+    lds_barrier();
     VT part;
     vzero(part);
 #pragma unroll
@@ -879,7 +894,7 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
     // aggregate of this block: the columns' partials meet in `red` (its own LDS array: no barrier is needed before
     // writing it), ONE barrier, then wave 0 sums over columns and over the RB row lanes of each tangent
     red[e * 64 + lane] = part;
-    __syncthreads();
+    lds_barrier();
     if (e == 0) {
         VT s = red[lane];
         for (int k = 1; k < c.n_e; k++) s = vadd(s, red[k * 64 + lane]);

@@ -125,7 +125,7 @@ def test_four_argument_backward_iteration_issues_one_sweep(hank):
     dseqs = hank.BackwardIteration(xd, {"Z": Z}, m, ss)
     dagg = hank.ForwardIteration(dseqs, m, ss)["KD"]
     assert hb.calls == {"primal": before["primal"], "jvp": before["jvp"], "primal_jvp": before["primal_jvp"] + 1}
-    assert np.array_equal(dagg.v, agg)
+    assert np.max(np.abs(dagg.v - agg)) <= 1e-13 * np.abs(agg).max()     # Dual pass (launches) vs Float64 pass (persistent sweeps): rounding
     # the five-argument form gives the same numbers
     ref = hank.ForwardIteration(hank.BackwardIteration(xd, {"Z": Z}, m, ss, ss_initial=ss), m, ss)["KD"]
     assert np.array_equal(ref.v, dagg.v) and np.array_equal(ref.p, dagg.p)

@@ -10,6 +10,13 @@ from conftest import ks_paths, ks_setup
 pytestmark = pytest.mark.gpu
 
 
+def same(a, b, rel=1e-13):
+    """equal to the rounding of the aggregate sums: the default schedule runs hank_primal / narrow hank_jvp batches as
+    XCD-local persistent sweeps and hank_primal_jvp / wide batches as per-period launches (same arithmetic per grid
+    point, different summation order over the grid)."""
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) <= rel * max(np.max(np.abs(b)), 1e-300)
+
+
 @pytest.fixture(scope="module")
 def big(hank):
     m, ss, orc = ks_setup(2000, 11, 300)
@@ -82,11 +89,11 @@ def test_benched_entry_primal_jvp_N32(big):
     same numbers as hank_primal + hank_jvp, and two of its columns against the oracle (NewtonRaphson.jl:95)."""
     m, ss, orc, hb, x, Z, y, agg, dagg = big
     agg2, dagg2 = hb.primal_jvp(x[2:4], y)
-    assert np.array_equal(agg2, agg) and np.array_equal(dagg2, dagg)
+    assert same(agg2, agg) and same(dagg2, dagg, 1e-12)
     oagg = _oracle_cols(orc, x[2:4], y, [5, 18], ss)
     assert np.max(np.abs(agg2 - oagg[:, 0])) < 1e-10 * np.abs(oagg[:, 0]).max()
     assert np.max(np.abs(dagg2[:, [5, 18]] - oagg[:, 1:])) < 1e-12 + 1e-10 * np.abs(oagg[:, 1:]).max()
-    assert np.array_equal(hb.jvp(y), dagg)            # the record it leaves serves later JVPs
+    assert same(hb.jvp(y), dagg, 1e-12)            # the record it leaves serves later JVPs
 
 
 def test_wide_batch_N256_full_size(big):
@@ -97,7 +104,7 @@ def test_wide_batch_N256_full_size(big):
     yw = np.random.default_rng(7).standard_normal((2, 299, N))
     yw[:, :, :32] = y                                  # the first 32 columns are the N=32 batch
     aggw, daggw = hb.primal_jvp(x[2:4], yw)
-    assert np.array_equal(aggw, agg)
+    assert same(aggw, agg)
     scale = np.abs(dagg).max()
     assert np.max(np.abs(daggw[:, :32] - dagg)) < 1e-12 + 1e-11 * scale      # same directions in another batch geometry
     oagg = _oracle_cols(orc, x[2:4], yw, [100, 255], ss)
@@ -131,6 +138,6 @@ def test_config4_hank_1000x7_T500():
     oagg = _oracle_cols(orc, x[:2], y[:2], [0, 31], ss, xt=x[2], yt=y[2])
     assert np.max(np.abs(agg - oagg[:, 0])) < 1e-10 * np.abs(oagg[:, 0]).max()
     assert np.max(np.abs(dagg[:, [0, 31]] - oagg[:, 1:])) < 1e-12 + 1e-10 * np.abs(oagg[:, 1:]).max()
-    assert np.array_equal(hb.primal(x), agg) and np.array_equal(hb.jvp(y), dagg)
+    assert same(hb.primal(x), agg) and same(hb.jvp(y), dagg, 1e-12)
     D = hb.dist_seq()
     np.testing.assert_allclose(D.sum(axis=(0, 1)), 1.0, atol=1e-11)

@@ -56,9 +56,10 @@ def test_household_block_matches_oracle(hank, hank_model, N):
     close(dagg, oagg[:, 1:1 + N])
     close(hb.policy_seq().transpose(2, 0, 1), opol[..., 0])
     close(hb.dpolicy_seq(N).transpose(2, 0, 1, 3), opol[..., 1:1 + N])
-    # the split schedule (hank_primal, then hank_jvp) gives the same numbers bit for bit
-    np.testing.assert_array_equal(hb.primal(x), agg)
-    np.testing.assert_array_equal(hb.jvp(y), dagg)
+    # hank_primal, then hank_jvp: the same numbers (to the rounding of the aggregate sums: the default schedule runs these
+    # two as XCD-local persistent sweeps and hank_primal_jvp as per-period launches)
+    close(hb.primal(x), agg, rel=1e-13)
+    close(hb.jvp(y), dagg, rel=1e-12)
 
 
 def test_transfer_tangent_against_central_differences(hank, hank_model):

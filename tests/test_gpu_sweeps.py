@@ -125,22 +125,38 @@ def test_knots_error_from_the_sweep(hank):
     hb.primal(x[2:4])                          # context recovers
 
 
+def _forced(hank, m, sched):
+    """a context of model m with one implementation forced for every entry point (HANK_SCHEDULE)."""
+    import os
+    wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    os.environ["HANK_SCHEDULE"] = sched
+    try:
+        return hank.HouseholdBlock(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+    finally:
+        os.environ.pop("HANK_SCHEDULE")
+
+
 def test_dual_sweep_equals_primal_then_jvp(hank):
-    """hank_primal_jvp (primal and tangents advancing in the same chain of launches) gives bit for bit
-    what hank_primal followed by hank_jvp gives, and leaves the same record behind."""
+    """hank_primal_jvp (value and partials in one pass) == hank_primal followed by hank_jvp, and it leaves the same record
+    behind: bit for bit within one implementation (per-period launches; XCD-local persistent sweeps), and to rounding of
+    the aggregate sums in the default schedule, which mixes the two (policies and their partials stay bit-identical)."""
     for (na, ne, T, N) in [(50, 2, 100, 3), (37, 3, 9, 5), (500, 4, 300, 1)]:
         m, ss, orc = ks_setup(na, ne, T)
         P = T - 1
         x, Z = ks_paths(m, ss, "x1", 0.05)
         y = np.random.default_rng(5).standard_normal((2, P, N))
-        hb = hank.household_block(m)
-        hb.set_boundary(ss.value, ss.D)
-        agg0 = hb.primal(x[2:4]); dagg0 = hb.jvp(y); pol0 = hb.policy_seq(); dpol0 = hb.dpolicy_seq(N)
-        hb.primal(x[2:4] * 1.01)                       # scramble the record
-        agg1, dagg1 = hb.primal_jvp(x[2:4], y)
-        assert np.array_equal(agg0, agg1) and np.array_equal(dagg0, dagg1)
-        assert np.array_equal(pol0, hb.policy_seq()) and np.array_equal(dpol0, hb.dpolicy_seq(N))
-        assert np.array_equal(hb.jvp(y), dagg0)        # the record it leaves serves later JVPs
+        for sched in ("launch", "xcd", None):
+            hb = _forced(hank, m, sched) if sched else hank.household_block(m)
+            same = np.array_equal if sched else (lambda a, b: np.max(np.abs(a - b)) <= 1e-13 * max(np.max(np.abs(b)), 1e-300))
+            hb.set_boundary(ss.value, ss.D)
+            agg0 = hb.primal(x[2:4]); dagg0 = hb.jvp(y); pol0 = hb.policy_seq(); dpol0 = hb.dpolicy_seq(N)
+            hb.primal(x[2:4] * 1.01)                       # scramble the record
+            agg1, dagg1 = hb.primal_jvp(x[2:4], y)
+            assert same(agg0, agg1) and same(dagg0, dagg1)
+            assert np.array_equal(pol0, hb.policy_seq()) and np.array_equal(dpol0, hb.dpolicy_seq(N))
+            assert same(hb.jvp(y), dagg0)                  # the record it leaves serves later JVPs
+            if sched:
+                hb.close()
 
 
 def test_alternating_batch_widths_reuse_workspaces(hank):
@@ -169,21 +185,16 @@ def test_alternating_batch_widths_reuse_workspaces(hank):
 
 
 def test_schedules_agree(hank):
-    """the XCD-local persistent sweeps (default) and the per-period launches (HANK_SCHEDULE=launch) are two
-    implementations of the same arithmetic: policies and their partials bit for bit, aggregates to summation order."""
-    import os
+    """the XCD-local persistent sweeps and the per-period launches are two implementations of the same arithmetic (the
+    default schedule picks per entry point and batch width): policies and their partials bit for bit, aggregates to
+    summation order."""
     m, ss, orc = ks_setup(500, 4, 300)
     P, N = 299, 12
     x, Z = ks_paths(m, ss, "x1", 0.01)
     y = np.random.default_rng(2).standard_normal((2, P, N))
-    wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
     res = {}
     for sched in ("xcd", "launch"):
-        os.environ["HANK_SCHEDULE"] = sched
-        try:
-            hb = hank.HouseholdBlock(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
-        finally:
-            os.environ.pop("HANK_SCHEDULE")
+        hb = _forced(hank, m, sched)
         hb.set_boundary(ss.value, ss.D)
         agg, dagg = hb.primal_jvp(x[2:4], y)
         assert hb.stats()["schedule"] == (1 if sched == "xcd" else 0) and hb.stats()["fallbacks"] == 0
