@@ -156,6 +156,14 @@ int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dp
 int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t max_iter, double *value_io, double *policy_out,
              int32_t *iters_out, double *supnorm_out);
 
+/* hank_stationary_dist: the stationary distribution of the steady state by the power method on the device — D <- Lambda D with
+ * the forward step of the hot path (Young lottery of `policy`[G] + exogenous transition), until two iterates
+ * `check_every` steps apart differ by less than `tol` (max norm) or `max_iter` steps. This is the iteration the host's
+ * invariant_dist uses for chains too large for the reference's direct solve (ForwardIteration.jl:436-442); same fixed
+ * point. D_io[G]: in = start (any positive vector), out = the last iterate (NOT normalised). */
+int hank_stationary_dist(hank_ctx *ctx, const double *policy, double *D_io, double tol, int32_t max_iter, int32_t check_every,
+                         int32_t *iters_out);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * Device time, in milliseconds, of the sweeps of the most recent hank_primal[_dev]/hank_jvp[_dev],
  * from HIP events recorded on the context's stream around each sweep:

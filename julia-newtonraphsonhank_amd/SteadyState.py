@@ -91,8 +91,13 @@ class SSAssembler:
                 if tol < self.vfi_tol:
                     break
                 res = vf.host_steady_state_step(value, xv, model)
-        Λ_endog = make_endogenous_transition(res[self.endog_dim.policy_var], self.endog_dim, self.n_exog)
-        D = invariant_dist((self.Λ_exog @ Λ_endog).T, D0=getattr(self, "_D_warm", None))
+        if self.vfi_on_device and self.endog_dim.n * self.n_exog > 4000:
+            # chains this large take the power method on the host too (invariant_dist): the same iteration, run with the
+            # forward step kernel of the hot path, warm-started from the last iterate
+            D, _ = hb.stationary_dist(res[self.endog_dim.policy_var], getattr(self, "_D_warm", None))
+        else:
+            Λ_endog = make_endogenous_transition(res[self.endog_dim.policy_var], self.endog_dim, self.n_exog)
+            D = invariant_dist((self.Λ_exog @ Λ_endog).T, D0=getattr(self, "_D_warm", None))
         self._D_warm = D
         for k in vars_of_type(model, "heterogeneous"):
             xv[k] = float(res[k].reshape(-1, order="F") @ D)
@@ -164,7 +169,11 @@ def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vf
     policies = {k: res[k] for k in het_keys}
     Λ_endog = make_endogenous_transition(policies[asm.endog_dim.policy_var], asm.endog_dim, asm.n_exog)
     Λss = (asm.Λ_exog @ Λ_endog).tocsc()
-    D = invariant_dist(Λss.T, D0=getattr(asm, "_D_warm", None))
+    if asm.vfi_on_device and asm.endog_dim.n * asm.n_exog > 4000:
+        from .BackwardIteration import household_block
+        D, _ = household_block(model).stationary_dist(policies[asm.endog_dim.policy_var], getattr(asm, "_D_warm", None))
+    else:
+        D = invariant_dist(Λss.T, D0=getattr(asm, "_D_warm", None))
     return SteadyState(vars_, policies, Λss, D, ss_value)
 
 

@@ -607,7 +607,8 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
-        const size_t lds = sizeof(double) * ((size_t)ps.D * c.n_e * 64 + (size_t)c.n_e * c.n_e + P + 3 * P * ps.D) + 64;
+        const int SLt = ps.D == 4 ? 6 : ps.D;      // XTileT<D>::SL
+        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + P + 3 * P * ps.D) + 64;
         if (X.maxt == 768) x_launch_tan<768>(ps.D, true, grd, blk, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, true, grd, blk, lds, s, ab, af);
     }
@@ -617,7 +618,8 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.N = ps.N; af.dpol = w->dpol + ps.dpol_off;
-        const size_t lds = sizeof(double) * ((size_t)ps.D * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * P * c.n_e + 64;
+        const int SLt = ps.D == 4 ? 6 : ps.D;
+        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * P * c.n_e + 64;
         if (X.maxt == 768) x_launch_tan<768>(ps.D, false, grd, blkF, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, false, grd, blkF, lds, s, ab, af);
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
@@ -1288,6 +1290,60 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
     if (iters_out) *iters_out = hstate[1];
     if (supnorm_out) *supnorm_out = hn;
     ctx->stats[5] += hstate[1];
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
+// ---- steady state: the stationary distribution by the power method on the device --------------------------------
+// D <- Lambda(policy) D (Young lottery + exogenous transition: the forward step kernel of the hot path) until two
+// iterates `check_every` steps apart differ by less than tol in the max norm, the rule of the host's power method
+// (GeneralStructures.py:invariant_dist, used where the reference's direct solve of ForwardIteration.jl:436-442 is too
+// large). The caller normalises the result.
+extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double *D_io, double tol, int32_t max_iter, int32_t check_every,
+                                    int32_t *iters_out) {
+    if (!ctx || !policy || !D_io || max_iter < 1 || check_every < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument");
+    const Consts &c = ctx->c;
+    const size_t G = c.G;
+    hipStream_t s = ctx->stream;
+    Scratch sc;
+    Record R{};      // ONE period of lottery record
+    double *D[2], *Dchk, *aggp, *norm;
+    int *state;
+    HIPC(ctx, sc.alloc(&R.pol, G)); HIPC(ctx, sc.alloc(&R.lw, G)); HIPC(ctx, sc.alloc(&R.ig, G)); HIPC(ctx, sc.alloc(&R.lo, G));
+    HIPC(ctx, sc.alloc(&R.start, (size_t)c.n_e * (c.n_a + 1))); HIPC(ctx, sc.alloc(&R.clo, c.n_e)); HIPC(ctx, sc.alloc(&R.seg, G));
+    HIPC(ctx, sc.alloc(&R.lwg, G));
+    HIPC(ctx, sc.alloc(&D[0], G)); HIPC(ctx, sc.alloc(&D[1], G)); HIPC(ctx, sc.alloc(&Dchk, G)); HIPC(ctx, sc.alloc(&aggp, ctx->nbp));
+    HIPC(ctx, sc.alloc(&norm, 1)); HIPC(ctx, sc.alloc(&state, 2));
+    HIPC(ctx, join_side(ctx));
+    HIPC(ctx, hipMemcpyAsync(R.pol, policy, sizeof(double) * G, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemcpyAsync(D[0], D_io, sizeof(double) * G, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemcpyAsync(Dchk, D_io, sizeof(double) * G, hipMemcpyHostToDevice, s));
+    HIPC(ctx, hipMemsetAsync(state, 0, 2 * sizeof(int), s));
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
+    hipLaunchKernelGGL(k_lottery, dim3((unsigned)c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, R, c.n_e, ctx->d_err);
+    HIPC(ctx, hipGetLastError());
+    const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
+    int hstate[2] = {0, 0}, done = 0;
+    while (!hstate[0] && done < max_iter) {
+        // a chunk = several checks; every check compares the iterate with the one check_every steps earlier
+        for (int q = 0; q < 16 && done < max_iter; q++) {
+            const int n = std::min((int)check_every, max_iter - done);
+            for (int k = 0; k < n; k++, done++)
+                hipLaunchKernelGGL(k_dist_iter, grd, blk, primal_lds(c), s, c, R, (const double *)D[done & 1], D[(done + 1) & 1], aggp, (const int *)state);
+            hipLaunchKernelGGL(k_vfi_check, dim3(1), dim3(1024), 0, s, (const double *)D[done & 1], (const double *)Dchk, (int)G, tol, state, norm);
+            HIPC(ctx, hipMemcpyAsync(Dchk, D[done & 1], sizeof(double) * G, hipMemcpyDeviceToDevice, s));
+        }
+        HIPC(ctx, hipGetLastError());
+        HIPC(ctx, hipMemcpyAsync(hstate, state, sizeof(hstate), hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipStreamSynchronize(s));
+    }
+    int e[4];
+    HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e[0] == ERR_NONMONO) return fail(ctx, HANK_ERR_NONMONOTONE, "savings policy is not monotone in wealth (productivity state %d, wealth index %d)", e[2] + 1, e[3] + 1);
+    // once converged the iteration kernels stop touching the buffers: Dchk holds the last checked iterate
+    HIPC(ctx, hipMemcpyAsync(D_io, Dchk, sizeof(double) * G, hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipStreamSynchronize(s));
+    if (iters_out) *iters_out = done;
     ctx->errmsg[0] = 0;
     return HANK_OK;
 }

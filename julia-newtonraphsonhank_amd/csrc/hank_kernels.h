@@ -386,19 +386,22 @@ __global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
 // block = RBP rows x n_e, thread (row, e) with row fastest (a 32-lane half-wave per column);
 // dynamic LDS: Dsh[n_e*RBP] + Pish[n_e*n_e] + red[16]
 // body shared by k_dist_step and k_fused_fwd; first RBP*n_e threads of block `bid` of `nblocks`
-__device__ inline void dist_step_body(const Consts &c, const Record &R, int t, double *aggpart, int bid, int nblocks, double *sh) {
+// Din / Dout (may be null): explicit D_{t-1} and D_t buffers instead of the record's Dseq rows — the stationary-distribution
+// iteration of the steady state reuses this step with one period's lottery and two ping-pong buffers
+__device__ inline void dist_step_body(const Consts &c, const Record &R, int t, double *aggpart, int bid, int nblocks, double *sh,
+                                      const double *Din = nullptr, double *Dout = nullptr) {
     double *Dsh = sh, *Pish = sh + c.n_e * RBP, *red = Pish + c.n_e * c.n_e;
     const int nthr = RBP * c.n_e;
     const int row = threadIdx.x % RBP, e = threadIdx.x / RBP;
     const int r = bid * RBP + row;
     const int n = c.n_a;
     for (int k = threadIdx.x; k < c.n_e * c.n_e; k += nthr) Pish[k] = c.Pi[k];
-    const double *Dprev = R.Dseq + (size_t)t * c.G;
+    const double *Dprev = Din ? Din : R.Dseq + (size_t)t * c.G;
     const size_t base = (size_t)t * c.G;
     const double *lw = R.lw + base + (size_t)e * n, *Dp = Dprev + (size_t)e * n;
     double acc = 0.0;
     if (r < n) {
-        R.lwg[base + (size_t)e * n + r] = make_double2(lw[r], R.ig[base + (size_t)e * n + r] * Dp[r]);
+        if (!Din) R.lwg[base + (size_t)e * n + r] = make_double2(lw[r], R.ig[base + (size_t)e * n + r] * Dp[r]);
         const int *st = R.start + ((size_t)t * c.n_e + e) * (n + 1);
         const int st1 = st[r], st2 = st[r + 1], st0 = r > 0 ? st[r - 1] : st1;
         for (int j = st0; j < st1; j++) acc += lw[j] * Dp[j];
@@ -419,7 +422,7 @@ __device__ inline void dist_step_body(const Consts &c, const Record &R, int t, d
         const int e2 = e;  // D_new[r,e2] = sum_e D_mid[r,e] * Pi[e,e2]
         double Dn = 0.0;
         Dn = mix_sum(Dn, Dsh + row, RBP, Pish + c.n_e * e2, 1, 0, c.n_e);
-        st_mode<HANK_ST_REC>(&R.Dseq[(size_t)(t + 1) * c.G + (size_t)e2 * n + r], Dn);
+        st_mode<HANK_ST_REC>(Dout ? &Dout[(size_t)e2 * n + r] : &R.Dseq[(size_t)(t + 1) * c.G + (size_t)e2 * n + r], Dn);
         part = R.pol[base + (size_t)e2 * n + r] * Dn;
     }
     const double tot = block_sum(part, red, nthr);
@@ -428,6 +431,12 @@ __device__ inline void dist_step_body(const Consts &c, const Record &R, int t, d
 __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
     extern __shared__ double sh[];
     dist_step_body(c, R, t, aggpart, blockIdx.x, gridDim.x, sh);
+}
+// one application of the (fixed) transition of record period 0 to an explicit distribution: D_out = Lambda D_in
+__global__ void k_dist_iter(Consts c, Record R, const double *Din, double *Dout, double *aggpart, const int *stop) {
+    extern __shared__ double sh[];
+    if (stop && *stop) return;
+    dist_step_body(c, R, 0, aggpart, blockIdx.x, gridDim.x, sh, Din, Dout);
 }
 
 // one convergence check of the steady state's inner fixed point (SteadyState.jl:136-139: max|value_new - value| < tol,

@@ -239,10 +239,17 @@ __device__ __forceinline__ double xwave_reduce63(double v) {
 // conflict-free for SL = 2, 4, 6). One pass over k serves the value and every partial.
 template <int D> struct XTile { static constexpr int SL = D == 0 ? 1 : (D == 1 ? 2 : (D == 2 ? 4 : (D == 4 ? 6 : D + 2))); };
 template <int SL>
-__device__ __forceinline__ void xtile_store(double *t, const double *v) {
+__device__ __forceinline__ void xtile_store(double *t, const double *v) {      // v holds SL values
     if (SL == 1) { t[0] = v[0]; return; }
 #pragma unroll
     for (int q = 0; q < SL / 2; q++) reinterpret_cast<double2 *>(t)[q] = make_double2(v[2 * q], v[2 * q + 1]);
+}
+template <int SL, int NS>
+__device__ __forceinline__ void xtile_store_n(double *t, const double *v) {    // v holds NS <= SL values; the padding slots stay unwritten
+    if (SL == 1) { t[0] = v[0]; return; }
+#pragma unroll
+    for (int q = 0; q < NS / 2; q++) reinterpret_cast<double2 *>(t)[q] = make_double2(v[2 * q], v[2 * q + 1]);
+    if (NS & 1) t[NS - 1] = v[NS - 1];
 }
 // out[s] = sum_k P[k*ps] * tile[k][lane][s], k ascending, first term unrounded-added (same order as mix_sum)
 template <int SL, int NS>
@@ -254,7 +261,7 @@ __device__ __forceinline__ void xtile_mix(const double *tl, const double *P, int
         if (SL == 1) v[0] = tl[(size_t)k * ks];
         else {
 #pragma unroll
-            for (int q = 0; q < SL / 2; q++) { const double2 d = reinterpret_cast<const double2 *>(tl + (size_t)k * ks)[q]; v[2 * q] = d.x; v[2 * q + 1] = d.y; }
+            for (int q = 0; q < (NS + 1) / 2; q++) { const double2 d = reinterpret_cast<const double2 *>(tl + (size_t)k * ks)[q]; v[2 * q] = d.x; v[2 * q + 1] = d.y; }
         }
         const double p = P[k * ps];
 #pragma unroll
@@ -710,7 +717,9 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
 // NewtonRaphson.jl:91-111; every pass of a wide batch) the primal sweep runs ONCE (the D = 0 instances above, which
 // also record the linearisation) and the partials run as pure linear recurrences: these two kernels. Same groups, same
 // state exchange through the XCD's L2, same barrier; per point and period a few FMAs per direction.
-template <int D> struct XTileT { static constexpr int SL = D; };     // slots of the tangent tile: D (1, 2, 4, 8)
+// slots of the tangent tile: D, padded where a lane stride of 8*D bytes would bank-conflict the 16-byte reads (D = 4: 32 B
+// -> lanes i and i+8 collide, 31 % of the LDS cycles in profiles/r02a; 48 B is conflict-free)
+template <int D> struct XTileT { static constexpr int SL = D == 4 ? 6 : (D == 8 ? 10 : D); };
 
 struct XTanBackArgs {
     Consts c;
@@ -769,7 +778,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
         double z[D];
 #pragma unroll
         for (int k = 0; k < D; k++) z[k] = 0.0;
-        if (!runahead) xtile_store<SL>(myt, z);         // dV_T = 0 (BackwardIteration.jl:85)
+        if (!runahead) xtile_store_n<SL, D>(myt, z);    // dV_T = 0 (BackwardIteration.jl:85)
     }
     __syncthreads();
     constexpr int NRA = MAXT == 768 ? 11 : 15;
@@ -837,7 +846,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                 xstore_row<D>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * D, dg);
             }
             XSTAMP(0, son, t, 1);
-            if (!runahead) xtile_store<SL>(myt, dV);
+            if (!runahead) xtile_store_n<SL, D>(myt, dV);
             XSTAMP(0, son, t, 2);
             XSTAMPW(0, son, t, 5, ne / 2);
             XSTAMPW(0, son, t, 6, ne - 1);
@@ -1029,7 +1038,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                     for (int k = 0; k < D; k++) acc[k] = cT[k];
                 }
             }
-            xtile_store<SL>(myt, acc);
+            xtile_store_n<SL, D>(myt, acc);
         }
         xlds_barrier();
         vnz = vnz_next;

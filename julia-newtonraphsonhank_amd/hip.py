@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
     "hank_primal_jvp", "hank_primal_jvp_dev",
     "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
-    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings", "hank_stats", "hank_vfi", "hank_device_available",
+    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings", "hank_stats", "hank_vfi", "hank_stationary_dist", "hank_device_available",
 )
 
 
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
     lib.hank_last_timings.argtypes = [vp, dp, C.POINTER(i32)]
     lib.hank_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.hank_vfi.argtypes = [vp, dp, C.c_double, i32, dp, dp, C.POINTER(i32), dp]
+    lib.hank_stationary_dist.argtypes = [vp, dp, dp, C.c_double, i32, i32, C.POINTER(i32)]
     lib.hank_device_available.argtypes = []
     for name in ABI_SYMBOLS:
         if name != "hank_last_error":
@@ -286,6 +287,17 @@ class HouseholdBlock:
         it, nrm = C.c_int32(), C.c_double()
         self._chk(self._lib.hank_vfi(self._ctx, _p(x), float(tol), int(max_iter), _p(v), _p(pol), C.byref(it), C.byref(nrm)))
         return v, pol, it.value, nrm.value
+
+    def stationary_dist(self, policy, D0=None, tol: float = 1e-15, max_iter: int = 500_000, check_every: int = 25):
+        """stationary distribution of the steady state by the power method on the device (hank_stationary_dist):
+        -> (D as a length-G vector summing to one, steps)."""
+        p = _f(policy, (self.n_a, self.n_e))
+        d = np.full(self.G, 1.0 / self.G) if D0 is None else np.asarray(D0, dtype=np.float64).reshape(-1, order="F") / np.sum(D0)
+        d = _f(d.reshape((self.n_a, self.n_e), order="F"))
+        it = C.c_int32()
+        self._chk(self._lib.hank_stationary_dist(self._ctx, _p(p), _p(d), float(tol), int(max_iter), int(check_every), C.byref(it)))
+        out = d.reshape(-1, order="F")
+        return out / out.sum(), it.value
 
     # -- granular steps ---------------------------------------------------------------------
     def backward_step(self, value_next, xhh_t):

@@ -53,4 +53,21 @@ def test_headline_steady_state_from_a_cold_start(hank):
     assert np.max(np.abs(ss.D - g["D"])) < 1e-8
     assert np.max(np.abs(ss.policies["KD"] - g["policy"])) < 1e-8 * np.abs(g["policy"]).max()
     print(f"2000x11 steady state, device VFI: {el:.2f} s")
-    assert el < 30.0
+    assert el < 10.0
+
+
+def test_device_stationary_distribution_matches_the_host(hank):
+    """hank_stationary_dist (power method with the forward step kernel) against the host's invariant_dist on the lottery
+    matrix of the same policy: same fixed point (both stop when iterates 25 steps apart agree to 1e-15)."""
+    import scipy.sparse as sp
+    m, ss, _ = ks_setup(500, 4, 300)
+    hb = hank.household_block(m)
+    pol = ss.policies["KD"]
+    D_dev, steps = hb.stationary_dist(pol)
+    wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    Λ_exog = sp.kron(sp.csc_matrix(pdm.transition.T), sp.identity(wd.n, format="csc"), format="csc")
+    Λ = (Λ_exog @ hank.make_endogenous_transition(pol, wd, pdm.n)).tocsc()
+    assert np.max(np.abs(Λ @ D_dev - D_dev)) < 1e-14            # a fixed point of the reference's transition matrix
+    assert abs(D_dev.sum() - 1.0) < 1e-14 and D_dev.min() >= 0.0
+    assert np.max(np.abs(D_dev - ss.D)) < 1e-10
+    assert steps > 25
