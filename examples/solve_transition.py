@@ -21,12 +21,19 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False):
+def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False, cold=False):
+    """cold=True: the steady state is solved here from the YAML guesses (value iteration and stationary distribution on
+    the device where one is present) instead of coming from the test fixtures' cache."""
     import hank_amd as h
     import hank_amd.parallel  # noqa: F401  (pulls in torch before the clocks start)
     from conftest import ks_setup
     t0 = time.perf_counter()
-    m, ss, _ = ks_setup(n_a, n_e, T)
+    if cold:
+        ov = {"T": T, "dimensions": {"wealth": {"n": n_a}, "productivity": {"n": n_e}}}
+        m = h.build_model_from_yaml(str(ROOT / "examples" / "krusell_smith.yaml"), overrides=ov)
+        ss, _ = h.get_SteadyStates(m)
+    else:
+        m, ss, _ = ks_setup(n_a, n_e, T)
     t_ss = time.perf_counter() - t0
     P = T - 1
     Z = 1.0 + shock * 0.8 ** np.arange(1, P + 1)                       # RunMain.jl:22-23
@@ -42,7 +49,7 @@ def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False):
     return {"grid": f"{n_a}x{n_e}", "T": T, "shock": f"Z_t = 1 + {shock}*0.8^t", "steady_state_s": round(t_ss, 3),
             "ss_jacobian_s": round(t_jac, 3), "newton_s": round(t_newton, 3),
             "newton_iterations": h.NewtonRaphsonHANK.iterations, "jvps": h.y_Iteration.total_jvps, "residual_norm": float(np.linalg.norm(lin.Fx)),
-            "wall_to_converged_path_s": round(t_jac + t_newton, 3)}, x
+            "wall_to_converged_path_s": round(t_jac + t_newton, 3), "steady_state": "cold start" if cold else "cached"}, x
 
 
 def solve_permanent(n_a=200, n_e=3, T=150, Z_end=1.03, eps=1e-9, verbose=False):
@@ -80,6 +87,7 @@ if __name__ == "__main__":
     ap.add_argument("--shock", type=float, default=0.01)
     ap.add_argument("--permanent", type=float, default=None, metavar="Z_END", help="two-steady-state scenario: Z jumps to Z_END for good")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--cold", action="store_true", help="solve the steady state from the YAML guesses (no fixture)")
     a = ap.parse_args()
     import os
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -92,7 +100,7 @@ if __name__ == "__main__":
     if a.permanent is not None:
         out = solve_permanent(a.n_a, a.n_e, a.T, a.permanent, verbose=a.verbose)[0]
     else:
-        out, x = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose)
+        out, x = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose, cold=a.cold)
     out["n_gpus"] = world
     if rank == 0:
         print(json.dumps(out))
