@@ -107,7 +107,7 @@ struct hank_ctx {
     // the persistent sweeps are supported): each entry point takes the faster of the two for its shape — see sched_*
     int schedule = 2;
     int last_tan = 0;              // which implementation ran the last tangent sweep (0 launches, 1 persistent): hank_get_dpolicy_seq
-    int xjvp_max = 16;             // auto: batches up to this width take the persistent tangent sweeps
+    int xjvp_max = 32;             // auto: batches up to this width take the persistent tangent sweeps (measured crossover)
     XWork xw;
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // see hank_stats
@@ -595,10 +595,10 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);     // (the primal may have been recorded by the launches)
     const dim3 grd(X.grid);
-    const char *ra = getenv("HANK_XRUNAHEAD");      // dev knob: bit 0 tangent backward, bit 1 tangent forward, bit 2 primal forward
-    const int ram = ra ? atoi(ra) : 0;
-    const bool fits = 64 * (c.n_e + 1) <= X.maxt;
-    const dim3 blk(((ram & 1) && fits) ? 64 * (c.n_e + 1) : 64 * c.n_e), blkF(((ram & 2) && fits) ? 64 * (c.n_e + 1) : 64 * c.n_e);
+    // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
+    const char *swv = getenv("HANK_XSYNCWAVE");
+    const bool fits = 64 * (c.n_e + 1) <= X.maxt && !(swv && atoi(swv) == 0);
+    const dim3 blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkF = blk;
     XTanBackArgs ab{};
     ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st_ds = X.st_ds;
     XTanFwdArgs af{};
@@ -734,7 +734,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
     HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_stream, hipEventDisableTiming));
     // schedule (measured on MI355X): "auto" wherever the grid fits one 63-row slab per CU of an XCD —
-    // the Float64 sweeps alone (hank_primal) and narrow tangent batches at a recorded primal (hank_jvp, N <= 16) run as
+    // the Float64 sweeps alone (hank_primal) and narrow tangent batches at a recorded primal (hank_jvp, N <= 32) run as
     // XCD-local persistent sweeps, the dual pass (hank_primal_jvp) and wide batches as per-period launches; both
     // read and write the same record. HANK_SCHEDULE=launch|xcd forces one implementation for everything (A-B, tests).
     const char *se = getenv("HANK_SCHEDULE");

@@ -174,6 +174,31 @@ __device__ __forceinline__ void xbarrier(XSync *sy, int x, int c, int members, u
     XSTAMP(sw, son, sper, 11);
 }
 
+// The same barrier in two halves, so that loads which do not depend on the other members (next period's record) can be
+// issued BETWEEN them and fly while the group meets: arrive = every storing wave drains, the workgroup meets; wait = the
+// SYNC wave (an extra wave with no memory traffic of its own where the block has room for one, else wave 0) publishes
+// this member's episode and polls the group's flags, then the workgroup meets again.
+__device__ __forceinline__ void xbar_arrive(bool drain) {
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    xlds_barrier();
+}
+__device__ __forceinline__ void xbar_wait(XSync *sy, int x, int c, int members, unsigned episode, bool sync_wave) {
+    if (sync_wave) {
+        const int lane = threadIdx.x & 63;
+        if (lane == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c]) = episode;
+        for (unsigned spins = 0;; spins++) {
+            const unsigned f = lane < members ? xldu(&sy->flag[x][lane]) : episode;
+            if (__all((int)(f - episode) >= 0)) break;
+            if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
+                if (lane == 0) xfail(sy, XERR_TIMEOUT, x);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    xlds_barrier();
+}
+
 // knots of one column, read from the L2-resident state. Everything egm_Y is going to look at in the usual case — the
 // row's own knot and its lower neighbour (sortedness check), the column's two end knots (flat extrapolation) and the
 // four knots around the guessed bracket — is fetched in ONE batch of independent loads up front: behind the branches
@@ -762,10 +787,11 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
         dxsh[(t_ * 3 + 2) * D + d_] = (on && c.n_hh > 2) ? A.dxt[ix] : 0.0;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool runahead = wv >= ne;                     // see k_xsweep_fwd: touches next period's record lines
-    const int e = runahead ? 0 : wv;
+    const bool syncw = wv >= ne;                        // the extra wave (when the block has one) only runs the group barrier's poll
+    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
+    const int e = syncw ? 0 : wv;
     const int r0 = cW * XRW, a = r0 + lane;
-    const bool own = !runahead && lane < XRW && a < na;
+    const bool own = !syncw && lane < XRW && a < na;
     const size_t pt = (size_t)e * na + (own ? a : 0);
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     const double ze = c.z[e], xa = c.a[own ? a : 0];
@@ -778,15 +804,11 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
         double z[D];
 #pragma unroll
         for (int k = 0; k < D; k++) z[k] = 0.0;
-        if (!runahead) xtile_store_n<SL, D>(myt, z);    // dV_T = 0 (BackwardIteration.jl:85)
+        if (!syncw) xtile_store_n<SL, D>(myt, z);       // dV_T = 0 (BackwardIteration.jl:85)
     }
     __syncthreads();
-    constexpr int NRA = MAXT == 768 ? 11 : 15;
-    int touched[NRA], sink_i = 0;
-#pragma unroll
-    for (int ee = 0; ee < NRA; ee++) touched[ee] = 0;
-    // the record of the period each half is about to use, fetched one trip ahead (its lines were touched by the
-    // run-ahead wave a period earlier)
+    // the record of the period each half is about to use, fetched one trip ahead: the loads are issued between the two
+    // halves of the group barrier and land while the group meets
     int ibY = 0;
     double cA = 0.0, cB = 0.0, cu = 0.0, cv = 0.0, ck = 0.0, cs = 0.0;
     if (own) { ck = R.kc[(size_t)(P - 1) * G + pt]; cs = R.s[(size_t)(P - 1) * G + pt]; }
@@ -796,32 +818,6 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0), one group barrier after every X
     for (int i = 0; i <= P; i++) {
         XSTAMP(0, son, P - i, 0);
-        if (runahead) {
-#pragma unroll
-            for (int ee = 0; ee < NRA; ee++) sink_i ^= touched[ee];
-            const int tn = P - 3 - i;                   // one trip AHEAD of the compute waves' own prefetch (Y record of tn+1, X record of tn)
-            if (tn + 1 >= 0) {
-                const int rows_here = min(XRW, na - r0);
-                int off = 0, len = 0;
-                if (lane < 4) { off = lane * 64; len = rows_here * 4; }
-                else if (lane < 52) { off = ((lane - 4) & 7) * 64; len = rows_here * 8; }
-#pragma unroll
-                for (int ee = 0; ee < NRA; ee++) {
-                    if (ee < ne) {
-                        const size_t elY = (size_t)(tn + 1) * G + (size_t)ee * na + r0, elX = (size_t)(tn > 0 ? tn : 0) * G + (size_t)ee * na + r0;
-                        const char *p;
-                        if (lane < 4) p = reinterpret_cast<const char *>(R.ib + elY);
-                        else if (lane < 12) p = reinterpret_cast<const char *>(R.A + elY);
-                        else if (lane < 20) p = reinterpret_cast<const char *>(R.B + elY);
-                        else if (lane < 28) p = reinterpret_cast<const char *>(R.u + elY);
-                        else if (lane < 36) p = reinterpret_cast<const char *>(R.v + elY);
-                        else if (lane < 44) p = reinterpret_cast<const char *>(R.kc + elX);
-                        else p = reinterpret_cast<const char *>(R.s + elX);
-                        if (lane < 52 && off < len) touched[ee] = *reinterpret_cast<const int *>(p + off);
-                    }
-                }
-            }
-        }
         if (i > 0) {
             // ---- Y-tangent of period t: dg = A ds[ib] + B ds[ib+1]; dV = u dr + v ((a dr + z dw + dtr) - dg)
             const int t = P - i, cur = (i - 1) & 1;
@@ -846,7 +842,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                 xstore_row<D>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * D, dg);
             }
             XSTAMP(0, son, t, 1);
-            if (!runahead) xtile_store_n<SL, D>(myt, dV);
+            if (!syncw) xtile_store_n<SL, D>(myt, dV);
             XSTAMP(0, son, t, 2);
             XSTAMPW(0, son, t, 5, ne / 2);
             XSTAMPW(0, son, t, 6, ne - 1);
@@ -867,17 +863,20 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                     ds[k] = ck * mx[k] - rho * ((ze * dw1 + dt1) + cs * dr1);
                 }
                 xstore_row<D>(sD + ((size_t)(i & 1) * hs + pt) * D, ds);
-                // the record the next trip needs: Y of period tx, X of period tx - 1
+            }
+            episode++;
+            XSTAMP(0, son, P - i, 4);
+            xbar_arrive(!syncw);
+            XSTAMP(0, son, P - i, 9);
+            if (own) {      // the record the next trip needs: Y of period tx, X of period tx - 1
                 const size_t ro = (size_t)tx * G + pt;
                 ibY = R.ib[ro]; cA = R.A[ro]; cB = R.B[ro]; cu = R.u[ro]; cv = R.v[ro];
                 if (tx > 0) { ck = R.kc[ro - G]; cs = R.s[ro - G]; }
             }
-            episode++;
-            XSTAMP(0, son, P - i, 4);
-            xbarrier(A.sy, x, cW, Sact, episode, 0, son, P - i, !runahead);
+            xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
+            XSTAMP(0, son, P - i, 11);
         }
     }
-    if (runahead && sink_i == 0x7f123457) A.dpol[0] = 1.0;      // (practically never true: keeps the touches)
 }
 
 struct XTanFwdArgs {
@@ -912,11 +911,12 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     if (cW >= Sact) return;
     for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool runahead = wv >= ne;
-    const int e = runahead ? 0 : wv;
+    const bool syncw = wv >= ne;                        // see k_xtan_back
+    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
+    const int e = syncw ? 0 : wv;
     const int r0 = cW * XRW, r = r0 + lane;
-    const bool own = !runahead && lane < XRW && r < na;
-    const bool virt = !runahead && lane == 63;
+    const bool own = !syncw && lane < XRW && r < na;
+    const bool virt = !syncw && lane == 63;
     const size_t pt = (size_t)e * na + (own ? r : 0);
     const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
@@ -931,12 +931,27 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
         for (int k = 0; k < D; k++) z[k] = 0.0;
         if (own || virt) xstore_row<D>(sT + slot * D, z);      // the initial distribution carries no partials
     }
-    unsigned episode = 1;
-    xbarrier(A.sy, x, cW, Sact, episode, 0, -1, -1, !runahead);
-    constexpr int NRA = MAXT == 768 ? 11 : 15;
-    int touched[NRA], touched2[NRA], sink_i = 0;
+    // this lane's own-row record of the period about to be processed (segments, policy, D_t, policy partials): fetched
+    // between the two halves of the previous group barrier
+    int4 sg = make_int4(0, 0, 0, 0);
+    double polr = 0.0, Dr = 0.0, dpr[D];
 #pragma unroll
-    for (int ee = 0; ee < NRA; ee++) touched[ee] = touched2[ee] = 0;
+    for (int k = 0; k < D; k++) dpr[k] = 0.0;
+    auto prefetch = [&](int t) {
+        if (own) {
+            const size_t base = (size_t)t * G + (size_t)e * na;
+            sg = R.seg[base + r];
+            polr = R.pol[base + r];
+            Dr = R.Dseq[base + G + r];                         // D_t[r] (row 0 includes what the primal kept on its virtual rows)
+            xload_row_plain<D>(A.dpol + (((size_t)t * A.groups + x) * G + (size_t)e * na + r) * D, dpr);
+        } else if (virt) {                                      // a virtual row carries row 0's policy
+            polr = R.pol[(size_t)t * G + (size_t)e * na];
+        }
+    };
+    unsigned episode = 1;
+    xbar_arrive(!syncw);
+    prefetch(0);
+    xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
     int cur = 0;
     bool vnz = false;
     for (int t = 0; t < P; t++) {
@@ -946,36 +961,10 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
         int clo = 0;
         bool vnz_next = false;
         for (int k = 0; k < ne; k++) vnz_next = vnz_next || closh[t * ne + k] > 0;
-        double acc[D], polr = 0.0, Dr = 0.0, dpr[D];
+        double acc[D];
 #pragma unroll
-        for (int k = 0; k < D; k++) acc[k] = dpr[k] = 0.0;
-        if (runahead) {
-#pragma unroll
-            for (int ee = 0; ee < NRA; ee++) sink_i ^= touched[ee] ^ touched2[ee];
-            if (t + 1 < P) {
-                const int rows_here = min(XRW, na - r0);
-                int off = 0, len = 0;
-                if (lane < 16) { off = lane * 64; len = rows_here * 16; }
-                else if (lane < 24) { off = (lane - 16) * 64; len = rows_here * 8; }
-                else if (lane < 40) { off = (lane - 24) * 64; len = rows_here * 16; }
-                else if (lane < 48) { off = (lane - 40) * 64; len = rows_here * 8; }
-                const int off2 = lane * 64, len2 = rows_here * 8 * D;
-#pragma unroll
-                for (int ee = 0; ee < NRA; ee++) {
-                    if (ee < ne) {
-                        const size_t el = (size_t)(t + 1) * G + (size_t)ee * na + r0;
-                        const char *p;
-                        if (lane < 16) p = reinterpret_cast<const char *>(R.seg + el);
-                        else if (lane < 24) p = reinterpret_cast<const char *>(R.pol + el);
-                        else if (lane < 40) p = reinterpret_cast<const char *>(R.lwg + el);
-                        else p = reinterpret_cast<const char *>(R.Dseq + el + G);
-                        if (lane < 48 && off < len) touched[ee] = *reinterpret_cast<const int *>(p + off);
-                        const char *q = reinterpret_cast<const char *>(A.dpol + (((size_t)(t + 1) * A.groups + x) * G + (size_t)ee * na + r0) * D);
-                        if (off2 < len2) touched2[ee] = *reinterpret_cast<const int *>(q + off2);
-                    }
-                }
-            }
-        } else {
+        for (int k = 0; k < D; k++) acc[k] = 0.0;
+        if (!syncw) {
             clo = min(max(closh[t * ne + e], 0), na);
             double vT[D];
 #pragma unroll
@@ -986,19 +975,16 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                 for (int k = 0; k < D; k++) vT[k] = xwave_sum(vT[k]);
             }
             if (own) {
-                int4 sg = R.seg[base + r];
-                sg.x = max(sg.x, 0); sg.z = min(sg.z, na);
-                polr = R.pol[base + r];
-                Dr = R.Dseq[base + G + r];                       // D_t[r] (the real row: row 0's virtual mass sits on the virtual lanes)
-                xload_row_plain<D>(A.dpol + (dbase + r) * D, dpr);
-                for (int j0 = sg.x; j0 < sg.z; j0 += 2) {
+                const int s0 = max(sg.x, 0), s2 = min(sg.z, na);   // (a record that is not a lottery must not turn into a long loop)
+                // sources two at a time: both sources' loads are in flight before either is used
+                for (int j0 = s0; j0 < s2; j0 += 2) {
                     double2 wg[2];
                     double dDj[2][D], dpj[2][D];
                     bool on[2];
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int j = j0 + u;
-                        on[u] = j < sg.z;
+                        on[u] = j < s2;
                         wg[u] = make_double2(0.0, 0.0);
 #pragma unroll
                         for (int k = 0; k < D; k++) dDj[u][k] = dpj[u][k] = 0.0;
@@ -1043,30 +1029,26 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
         xlds_barrier();
         vnz = vnz_next;
         const int nxt = cur ^ 1;
-        if (!runahead) {
+        if (!syncw) {
             double mx[D];
             xtile_mix<SL, D>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
             if (own || virt) xstore_row<D>(sT + ((size_t)nxt * hs + slot) * D, mx);
-            double pol_here = polr, D_here = Dr, dp_here[D];
-#pragma unroll
-            for (int k = 0; k < D; k++) dp_here[k] = dpr[k];
-            if (virt) {          // a virtual row carries row 0's policy; its share of D_t[0] is already in the recorded D_t[0]
-                pol_here = R.pol[base];
-                D_here = 0.0;
-            }
+            // aggregate partials: pol_t dD_t + dpol_t D_t on real rows; a virtual row carries row 0's policy, its share of
+            // D_t[0] is already in the recorded D_t[0]
             const bool live = own || virt;
             const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
 #pragma unroll
             for (int k = 0; k < D; k++) {
-                const double pd = xwave_reduce63(live ? (pol_here * mx[k] + dp_here[k] * D_here) : 0.0);
+                const double pd = xwave_reduce63(live ? (polr * mx[k] + (own ? dpr[k] * Dr : 0.0)) : 0.0);
                 if (lane == 63) A.daggpart[pb * (size_t)(XG * D) + x * D + k] = pd;
             }
         }
         cur = nxt;
         episode++;
-        xbarrier(A.sy, x, cW, Sact, episode, 1, -1, -1, !runahead);
+        xbar_arrive(!syncw);
+        if (t + 1 < P) prefetch(t + 1);
+        xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
     }
-    if (runahead && sink_i == 0x7f123457) A.daggpart[0] = 1.0;
 }
 
 // rho_t = 1/(1+r_t) for every period (the X half's discounting; same expression as egm_X)
