@@ -33,10 +33,12 @@ constexpr int XRW = 63;           // wealth rows per workgroup; lane 63 of every
 constexpr unsigned XSPIN_LIMIT = 1u << 21;
 enum { XERR_TIMEOUT = 1, XERR_PLACEMENT = 2 };
 
-struct XSync {                    // zeroed by a memset node before EVERY launch (3456 B, a multiple of 16)
+struct XSync {                    // zeroed by a memset node before EVERY launch (66.9 KB, a multiple of 16)
     unsigned ticket[XG][32];      // [x][0]: workgroups that arrived on XCD x (one 128-B line each)
     unsigned total[32];           // [0]: workgroups that hold a ticket
-    unsigned flag[XG][64];        // [x][c]: the last barrier episode member c of group x has reached
+    unsigned flag[XG][64][32];    // [x][c][0]: the last barrier episode member c of group x has reached — one 128-B line per
+                                  // member: 32 writers and 32 pollers on ONE line queue at one L2 channel (1.0-1.15 us per
+                                  // episode against 0.71, scripts/ubench/xbar_bench.hip)
     unsigned status[32];          // [0]: XERR_* (sticky), [1]: the XCD that raised it
     unsigned pad[32];
 };
@@ -158,9 +160,9 @@ __device__ __forceinline__ void xbarrier(XSync *sy, int x, int c, int members, u
     xlds_barrier();
     XSTAMP(sw, son, sper, 9);
     if (threadIdx.x < 64) {
-        if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c]) = episode;
+        if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c][0]) = episode;
         for (unsigned spins = 0;; spins++) {
-            const unsigned f = (int)threadIdx.x < members ? xldu(&sy->flag[x][threadIdx.x]) : episode;
+            const unsigned f = (int)threadIdx.x < members ? xldu(&sy->flag[x][threadIdx.x][0]) : episode;
             if (__all((int)(f - episode) >= 0)) break;
             if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
                 if (threadIdx.x == 0) xfail(sy, XERR_TIMEOUT, x);
@@ -185,9 +187,9 @@ __device__ __forceinline__ void xbar_arrive(bool drain) {
 __device__ __forceinline__ void xbar_wait(XSync *sy, int x, int c, int members, unsigned episode, bool sync_wave) {
     if (sync_wave) {
         const int lane = threadIdx.x & 63;
-        if (lane == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c]) = episode;
+        if (lane == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c][0]) = episode;
         for (unsigned spins = 0;; spins++) {
-            const unsigned f = lane < members ? xldu(&sy->flag[x][lane]) : episode;
+            const unsigned f = lane < members ? xldu(&sy->flag[x][lane][0]) : episode;
             if (__all((int)(f - episode) >= 0)) break;
             if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
                 if (lane == 0) xfail(sy, XERR_TIMEOUT, x);
@@ -954,7 +956,10 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
     int cur = 0;
     bool vnz = false;
+    const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact / 3) ? 1 : -1);
+    (void)son;
     for (int t = 0; t < P; t++) {
+        XSTAMP(1, son, t, 0);
         const size_t base = (size_t)t * G + (size_t)e * na;
         const size_t hb = (size_t)cur * hs;
         const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;
@@ -1009,6 +1014,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                     }
                 }
             }
+            XSTAMP(1, son, t, 1);
             {   // the mass point (see k_xsweep_fwd)
                 double cT[D];
 #pragma unroll
@@ -1024,9 +1030,13 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                     for (int k = 0; k < D; k++) acc[k] = cT[k];
                 }
             }
+            XSTAMP(1, son, t, 2);
             xtile_store_n<SL, D>(myt, acc);
         }
+        XSTAMPW(1, son, t, 6, ne - 1);
+        XSTAMPW(1, son, t, 7, ne / 2);
         xlds_barrier();
+        XSTAMP(1, son, t, 3);
         vnz = vnz_next;
         const int nxt = cur ^ 1;
         if (!syncw) {
@@ -1045,9 +1055,12 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
         }
         cur = nxt;
         episode++;
+        XSTAMP(1, son, t, 4);
         xbar_arrive(!syncw);
+        XSTAMP(1, son, t, 9);
         if (t + 1 < P) prefetch(t + 1);
         xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
+        XSTAMP(1, son, t, 11);
     }
 }
 

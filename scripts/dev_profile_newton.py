@@ -4,7 +4,9 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import hank_amd as h
 import hank_amd.parallel
 from conftest import ks_setup
-m, ss, _ = ks_setup(500, 4, 300)
+import os
+NA, NE = (int(v) for v in os.environ.get("GRID", "500x4").split("x"))
+m, ss, _ = ks_setup(NA, NE, 300)
 P = 299
 Z = 1.0 + 0.01 * 0.8 ** np.arange(1, P + 1)
 x0 = np.tile(np.array([ss.vars[k] for k in ("Y", "KS", "r", "w")]), P)

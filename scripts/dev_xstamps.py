@@ -30,12 +30,12 @@ hb._lib.hank_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert hb._lib.hank_debug_stamps(hb._ctx, buf) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(2, 2, 8, 12).astype(np.int64)
 names = {0: ["top", "egm_Y done", "dpol+LDS issued", "after WG barrier", "X half issued", "wave ne/2 at LDS barrier", "wave ne-1 at LDS barrier", "run-ahead wave at LDS barrier", "stores drained (vmcnt0)", "WG barrier", "polled (tid0)", "barrier exit"],
-         1: ["top", "sources done", "mass point done", "tile+WG barrier", "mix+stores issued", "agg partials issued", "", "", "stores drained (vmcnt0)", "WG barrier", "polled (tid0)", "barrier exit"]}
+         1: ["top", "sources done", "mass point done", "after LDS barrier", "mix+stores+agg issued", "", "wave ne-1 at LDS barrier", "wave ne/2 at LDS barrier", "", "arrived (drain + WG barrier)", "", "barrier exit"]}
 tick_ns = 10.0      # s_memtime counts at 100 MHz on gfx950 (constant clock)
 for sw, sname in ((0, "backward"), (1, "forward")):
-    for mem, mname in ((0, "first member"), (1, "last member")):
+    for mem, mname in ((0, "first member"), (1, "member at a third of the grid")):
         s_ = st[sw, mem]
-        order = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11] if sw == 1 else [0, 1, 2, 5, 6, 7, 3, 4, 8, 9, 10, 11]
+        order = [0, 1, 2, 6, 7, 3, 4, 9, 11] if sw == 1 else [0, 1, 2, 5, 6, 3, 4, 9, 11]
         print(f"--- {sname}, {mname}, N={N}: ns since period top (median over {s_.shape[0]} periods); period length = next top - top")
         rel = (s_[:, order] - s_[:, [0]]) * tick_ns
         med = np.median(rel, axis=0)
