@@ -946,6 +946,10 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
             polr = R.pol[base + r];
             Dr = R.Dseq[base + G + r];                         // D_t[r] (row 0 includes what the primal kept on its virtual rows)
             xload_row_plain<D>(A.dpol + (((size_t)t * A.groups + x) * G + (size_t)e * na + r) * D, dpr);
+            // this row is somebody's SOURCE next period: its lottery record is only ever read as a source (cold from HBM
+            // inside the source loop otherwise) — touching it here puts the line into the XCD's L2 for whoever needs it
+            const double2 wtouch = R.lwg[base + r];
+            asm volatile("" ::"v"(wtouch.x), "v"(wtouch.y));
         } else if (virt) {                                      // a virtual row carries row 0's policy
             polr = R.pol[(size_t)t * G + (size_t)e * na];
         }
