@@ -22,6 +22,8 @@ def test_clone_gives_identical_results_and_is_independent(hank):
         np.testing.assert_array_equal(d1, d2)
         # the clone keeps its own primal: moving one context does not disturb the other
         hb2.primal(x[2:4] * 1.01)
-        np.testing.assert_array_equal(hb.jvp(y), d1)
+        again = hb.jvp(y)      # (default schedule: a narrow hank_jvp runs as persistent sweeps, d1 came from the dual-sweep launches)
+        assert np.max(np.abs(again - d1)) <= 1e-13 * np.abs(d1).max()
+        np.testing.assert_array_equal(hb.jvp(y), again)
     finally:
         hb2.close()
