@@ -52,6 +52,22 @@ def load_or_solve_ss(n_a, n_e, T):
     return m, ss
 
 
+def check_timed_output(m, ss, x, dx_host, agg_gpu, dagg_gpu):
+    """the output of the LAST timed step against the CPU oracle (value and the first tangent column; oracle = checker only)."""
+    from oracle.oracle import Oracle
+    wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    orc = Oracle(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons)
+    P = m.compspec.T - 1
+    xr = np.zeros((P, 2)); xw = np.zeros((P, 2))
+    xr[:, 0], xw[:, 0] = x[2], x[3]
+    xr[:, 1], xw[:, 1] = dx_host[0, :, 0], dx_host[1, :, 0]
+    st, oagg, _ = orc.household_block(xr, xw, ss.value, ss.D, 1)
+    return {"oracle_status": int(st),
+            "agg_max_rel_err": float(np.max(np.abs(agg_gpu - oagg[:, 0])) / np.abs(oagg[:, 0]).max()),
+            "dagg_col0_max_rel_err": float(np.max(np.abs(dagg_gpu[:, 0] - oagg[:, 1])) / np.abs(oagg[:, 1]).max()),
+            "tolerance": 1e-10}
+
+
 def cpu_baseline(m, ss, x, Z, budget_s=12.0):
     """the reference-style CPU path (oracle: dual numbers, primal recomputed on every JVP,
     NewtonRaphson.jl:95) timed on a bounded sample of the same workload: on ONE host core (the
@@ -179,8 +195,8 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="ks_2000x11_T300_N32", choices=sorted(WORKLOADS))
     ap.add_argument("--tangents", type=int, default=None, help="override the per-GPU tangent batch width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -219,7 +235,8 @@ def main():
     # synthetic inputs, resident in HBM: household inputs (r_t, w_t) and this rank's tangent columns
     rng = np.random.default_rng(1000 + rank)
     d_x = torch.from_numpy(np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()).to(dev)
-    d_dx = torch.from_numpy(rng.standard_normal(2 * P * N)).to(dev)     # (2, P, N) column-major
+    dx_flat = rng.standard_normal(2 * P * N)
+    d_dx = torch.from_numpy(dx_flat).to(dev)     # (2, P, N) column-major
     d_agg = torch.empty(P, dtype=torch.float64, device=dev)
     d_dagg = torch.empty(P * N, dtype=torch.float64, device=dev)        # (P, N) column-major
     d_all = torch.empty(world * P * N, dtype=torch.float64, device=dev) if use_dist else None
@@ -329,6 +346,9 @@ def main():
             "sweeps_ms": {k: round(acc[k], 4) for k in acc}, "launches": launches,
         }
         if not args.no_cpu_baseline and world == 1:
+            step(); fence()          # the benched call once more, its outputs against the CPU oracle
+            out["output_check"] = check_timed_output(m, ss, x, dx_flat.reshape((2, P, N), order="F"), d_agg.cpu().numpy(),
+                                                     d_dagg.cpu().numpy().reshape((P, N), order="F"))
             out["cpu_baseline"] = cpu_baseline(m, ss, x, Z)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         if not args.no_extra and world == 1:

@@ -141,6 +141,15 @@ static int fail(hank_ctx *ctx, int code, const char *fmt, ...) {
                         __FILE__, __LINE__, #call);                                             \
     } while (0)
 
+// a context is bound to the HIP device that was current at hank_create: calling it with another device current would
+// launch on that other device with this one's pointers
+#define ENTER(ctx)                                                                                                    \
+    do {                                                                                                              \
+        int dev_ = -1;                                                                                                \
+        if ((ctx) && hipGetDevice(&dev_) == hipSuccess && dev_ != (ctx)->device)                                      \
+            return fail(ctx, HANK_ERR_BAD_ARG, "context is bound to HIP device %d, the current device is %d", (ctx)->device, dev_); \
+    } while (0)
+
 template <typename T>
 static hipError_t dmalloc(T **p, size_t count) {
     return hipMalloc((void **)p, count * sizeof(T) > 0 ? count * sizeof(T) : 8);
@@ -800,6 +809,7 @@ int hank_sync(hank_ctx *ctx) {
 }
 
 int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *ss_init_D) {
+    ENTER(ctx);
     if (!ctx || !ss_end_value || !ss_init_D) return fail(ctx, HANK_ERR_BAD_ARG, "null boundary pointer");
     const size_t G = ctx->c.G;
     HIPC(ctx, join_side(ctx));
@@ -885,6 +895,7 @@ static bool x_fallback_allowed() {
 }
 
 int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
+    ENTER(ctx);
     if (!ctx || !d_xhh) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
     if (use_x_primal(ctx)) return x_primal(ctx, d_xhh, hipMemcpyDeviceToDevice, d_agg_out);
@@ -894,11 +905,13 @@ int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
 }
 
 int hank_check(hank_ctx *ctx) {
+    ENTER(ctx);
     if (!ctx) return HANK_ERR_BAD_ARG;
     return fetch_device_error(ctx);
 }
 
 int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
+    ENTER(ctx);
     if (!ctx || !xhh) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
     const size_t P = ctx->c.P;
@@ -951,6 +964,7 @@ static int run_jvp(hank_ctx *ctx) {
 }
 
 int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_out) {
+    ENTER(ctx);
     if (!ctx || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
     if (use_x_jvp(ctx, N)) return x_dual(ctx, nullptr, d_dxhh, hipMemcpyDeviceToDevice, N, nullptr, d_dagg_out);
@@ -965,6 +979,7 @@ int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_
 }
 
 int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
+    ENTER(ctx);
     if (!ctx || !dxhh || !dagg_out || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
     const size_t P = ctx->c.P;
@@ -1023,6 +1038,7 @@ static int run_fused(hank_ctx *ctx) {
 
 int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh, int32_t N, double *d_agg_out,
                         double *d_dagg_out) {
+    ENTER(ctx);
     if (!ctx || !d_xhh || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
     if (use_x_fused(ctx)) return x_dual(ctx, d_xhh, d_dxhh, hipMemcpyDeviceToDevice, N, d_agg_out, d_dagg_out);
@@ -1040,6 +1056,7 @@ int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh
 }
 
 int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_t N, double *agg_out, double *dagg_out) {
+    ENTER(ctx);
     if (!ctx || !xhh || !dxhh || !dagg_out || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
     const size_t P = ctx->c.P;
@@ -1176,6 +1193,8 @@ static int granular_backward(hank_ctx *ctx, const double *value_next, const doub
                              double *dvalue_out, double *policy_out, double *dpolicy_out) {
     if (!ctx || !value_next || !xhh_t || !value_out || !policy_out) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
     if (N > 0 && (!dvalue_next || !dxhh_t || !dvalue_out || !dpolicy_out)) return fail(ctx, HANK_ERR_BAD_ARG, "null tangent pointer");
+    ENTER(ctx);
+    { const bool pd = ctx->primal_done; const int pend = fetch_device_error(ctx); if (pend) return pend; ctx->primal_done = pd; }   // an error a preceding async sweep left is reported, not overwritten
     const Consts &c = ctx->c;
     const size_t G = c.G;
     hipStream_t s = ctx->stream;
@@ -1241,6 +1260,8 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
                         int32_t *iters_out, double *supnorm_out) {
     if (!ctx || !xhh_t || !value_io || !policy_out || max_iter < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument");
     if (!(1.0 + xhh_t[0] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive");
+    ENTER(ctx);
+    { const bool pd = ctx->primal_done; const int pend = fetch_device_error(ctx); if (pend) return pend; ctx->primal_done = pd; }
     const Consts &c = ctx->c;
     const size_t G = c.G;
     hipStream_t s = ctx->stream;
@@ -1302,6 +1323,8 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
 extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double *D_io, double tol, int32_t max_iter, int32_t check_every,
                                     int32_t *iters_out) {
     if (!ctx || !policy || !D_io || max_iter < 1 || check_every < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument");
+    ENTER(ctx);
+    { const bool pd = ctx->primal_done; const int pend = fetch_device_error(ctx); if (pend) return pend; ctx->primal_done = pd; }
     const Consts &c = ctx->c;
     const size_t G = c.G;
     hipStream_t s = ctx->stream;
