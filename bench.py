@@ -352,7 +352,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(m, ss, x, Z)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         if not args.no_extra and world == 1:
-            out["extra"] = extra_measurements(hb, d_x, P, N, dev, stream.cuda_stream)
+            try:
+                out["extra"] = extra_measurements(hb, d_x, P, N, dev, stream.cuda_stream)
+            except Exception as e:      # noqa: BLE001 - the headline line must survive a failure of the side measurements
+                out["extra"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -508,11 +508,10 @@ static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
 }
 
 
-// the primal sweeps are the D = 0 instances of the dual kernels (hank_xsweep.h)
 template <int MAXT>
 static void x_launch_primal(bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XBackArgs &ab, const XFwdArgs &af) {
-    if (back) hipLaunchKernelGGL((k_xsweep_back<0, MAXT>), grd, blk, lds, s, ab);
-    else hipLaunchKernelGGL((k_xsweep_fwd<0, MAXT>), grd, blk, lds, s, af);
+    if (back) hipLaunchKernelGGL((k_xprimal_back<MAXT>), grd, blk, lds, s, ab);
+    else hipLaunchKernelGGL((k_xprimal_fwd<MAXT>), grd, blk, lds, s, af);
 }
 template <int MAXT>
 static void x_launch_tan(int D, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XTanBackArgs &ab, const XTanFwdArgs &af) {
@@ -552,17 +551,15 @@ static int x_run_primal(hank_ctx *ctx) {
     HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync) * 2, s));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
-    const dim3 grd(X.grid), blk(64 * c.n_e);
-    const char *ra = getenv("HANK_XRUNAHEAD");      // dev knob: bit 0 tangent backward, bit 1 tangent forward, bit 2 primal forward
-    const int ram = ra ? atoi(ra) : 0;      // measured: the extra wave is the straggler of every workgroup barrier
-    const dim3 blkf(((ram & 4) && 64 * (c.n_e + 1) <= X.maxt) ? 64 * (c.n_e + 1) : 64 * c.n_e);     // + the run-ahead wave where it fits
+    // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
+    const char *swv = getenv("HANK_XSYNCWAVE");
+    const bool fits = 64 * (c.n_e + 1) <= X.maxt && !(swv && atoi(swv) == 0);
+    const dim3 grd(X.grid), blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkf = blk;
     XBackArgs ab{};
-    ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.rho = X.rho; ab.Ntot = 1; ab.n0 = 0; ab.N = 0;
-    ab.sy = X.sync; ab.st_s = X.st_s; ab.st_ds = X.st_ds; ab.pol = ctx->R.pol; ab.dpol = nullptr; ab.groups = 1;
+    ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.rho = X.rho; ab.sy = X.sync; ab.st_s = X.st_s;
     ab.err = ctx->d_err; ab.R = ctx->R;
     XFwdArgs af{};
-    af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.sy = X.sync + 1; af.st_D = X.st_D; af.st_dD = X.st_dD; af.dpol = nullptr;
-    af.groups = 1; af.N = 0; af.Dseq = ctx->R.Dseq; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart; af.daggpart = nullptr; af.record = 1;
+    af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.sy = X.sync + 1; af.st_D = X.st_D; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart;
     const size_t ldsb = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * P) + 64;
     const size_t ldsf = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * P * c.n_e + 64;
     HIPC(ctx, hipEventRecord(ctx->ev[0], s));

@@ -1,28 +1,35 @@
-// hank_xsweep.h — the XCD-local persistent DUAL sweeps: ONE launch per sweep instead of one per period.
+// hank_xsweep.h — the XCD-local persistent sweeps: ONE launch per sweep instead of one per period.
 //
-// What the reference does under Dual{Tag,Float64,N} (NewtonRaphson.jl:95: value and partials travel together through
-// BackwardIteration.jl:90-113 and ForwardIteration.jl:297-308) is done here literally: every workgroup carries the
-// Float64 recurrence AND D partials for its grid points, period after period, inside one kernel.
+// The same recurrences as hank_kernels.h (BackwardIteration.jl:90-113, ForwardIteration.jl:297-308 and their partials
+// under Dual{Tag,Float64,N}), behind the same entry points and on the same record, as four persistent kernels:
+//   k_xprimal_back / k_xprimal_fwd : the Float64 recurrences (they record the linearisation),
+//   k_xtan_back<D> / k_xtan_fwd<D> : the N partials as linear recurrences at that record (the whole y-iteration keeps x
+//                                    fixed, NewtonRaphson.jl:91-111; so does every pass of a wide batch).
 //
 // Mapping (MI355X: 8 XCDs x 32 CUs, one 4 MiB L2 per XCD, L2s not coherent with each other):
 //   * a launch has one workgroup per CU; each workgroup reads the XCD it actually runs on (HW_REG_XCC_ID) and takes a
 //     ticket there: the workgroups of one XCD form a GROUP. Nothing assumes a placement — a group that does not have
 //     the members it needs reports XERR_PLACEMENT and the host falls back to the per-period launches.
-//   * group x owns the tangent directions [x*D, (x+1)*D) of the batch (D = 1, 2, 4 or 8); the Float64 recurrence is
-//     computed redundantly by every group (it is 1/(1+D) of the arithmetic and none of the HBM traffic).
 //   * inside a group, workgroup c owns 63 wealth rows (all n_e productivity columns: wave = column, lane = row).
-//   * the loop-carried state (EGM knots s_t and their partials ds_t backward; D_t and dD_t forward) lives in a small
-//     ping-pong buffer that never leaves the XCD's L2: written with plain stores, read back — after ONE group barrier
-//     per period — with sc1 loads, which bypass the reading CU's L1 and are served by that same L2. No kernel boundary,
-//     no cross-XCD traffic, no fence: the only HBM streams are the algorithmic ones (the policy-partials sequence,
-//     written once backward and read once forward) plus the policy / lottery records.
-//   * group barrier = every wave drains its stores (vmcnt(0)), workgroup barrier, one lane adds to the group's counter
-//     and polls it. Every spin is bounded; on timeout a status word is set and every later wait falls through, so the
-//     grid always drains.
+//   * tangent sweeps: group x owns the directions [x*D, (x+1)*D) of the pass (D = 1, 2 or 4; 8*D directions per pass);
+//     Float64 sweeps: the group of XCD 0 runs them, the other workgroups leave at once.
+//   * the loop-carried state (EGM knots s_t / their partials ds_t backward; D_t / dD_t forward) lives in a small
+//     ping-pong buffer in the XCD's L2: written with plain stores (the line stays in that L2), read back — after ONE
+//     group barrier per period — with sc1 loads, which bypass the reading CU's L1 and are served by that same L2. No
+//     kernel boundary, no fence, no atomics in the loop.
+//   * group barrier: every storing wave drains (vmcnt(0)), raw s_barrier, the member publishes the episode number in ITS
+//     flag line with a plain store, one wave polls all members' lines with one sc1 load per trip, s_barrier. It comes in
+//     two halves (arrive / wait) so that loads which do not depend on the other members fly while the group meets.
+//     Every spin is bounded; on timeout a status word is set and every later wait falls through: the grid always drains.
+//   * what a period reads that is uniform over the workgroup (r_t, w_t, rho_t, dr/dw/dtr of the group, the clamped prefix
+//     lengths) is LDS-resident for the whole sweep: as a per-period global load each is a cold round trip on the
+//     critical path.
 //
 // Layouts:  state  st_s [2][XG][G], st_ds [2][XG][G][D]                       (backward)
 //                  st_D [2][XG][G+64*n_e], st_dD [2][XG][G+64*n_e][D]         (forward; the tail holds the virtual rows)
 //           dpol   [P][groups][n_e][n_a][D]   — a group's stream is contiguous: whole lines, one XCD each.
+// What was measured on the way (a dual kernel carrying value and partials together, a run-ahead wave, atomic-counter
+// barriers, ...) is in DESIGN.md section 4.
 #pragma once
 #include "hank_kernels.h"
 
@@ -149,34 +156,10 @@ __device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
 // (__syncthreads() carries a fence that drains vmcnt: the dpol stores and the run-ahead touches would stall here)
 __device__ __forceinline__ void xlds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// one episode of the group barrier. No atomics (they execute at the memory side, a fabric round trip each): member c
-// publishes the episode number in ITS word of the group's flag line with a plain store — the line lives in the XCD's
-// L2 like the state itself — and wave 0 of every member polls all members' words with ONE sc1 load per trip.
-// `drain` = false only for a wave that has stored nothing since the last episode (the run-ahead wave: its loads stay in
-// flight across the barrier).
-__device__ __forceinline__ void xbarrier(XSync *sy, int x, int c, int members, unsigned episode, int sw = 0, int son = -1, int sper = -1, bool drain = true) {
-    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave: its stores have reached L2
-    XSTAMP(sw, son, sper, 8);
-    xlds_barrier();
-    XSTAMP(sw, son, sper, 9);
-    if (threadIdx.x < 64) {
-        if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c][0]) = episode;
-        for (unsigned spins = 0;; spins++) {
-            const unsigned f = (int)threadIdx.x < members ? xldu(&sy->flag[x][threadIdx.x][0]) : episode;
-            if (__all((int)(f - episode) >= 0)) break;
-            if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
-                if (threadIdx.x == 0) xfail(sy, XERR_TIMEOUT, x);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    XSTAMP(sw, son, sper, 10);
-    xlds_barrier();
-    XSTAMP(sw, son, sper, 11);
-}
-
-// The same barrier in two halves, so that loads which do not depend on the other members (next period's record) can be
+// The group barrier. No atomics (they execute at the memory side, a fabric round trip each): member c publishes the episode
+// number in ITS flag line with a plain store — the line lives in the XCD's L2 like the state itself — and one wave of
+// every member polls all members' lines with ONE sc1 load per trip.
+// It comes in two halves, so that loads which do not depend on the other members (next period's record) can be
 // issued BETWEEN them and fly while the group meets: arrive = every storing wave drains, the workgroup meets; wait = the
 // SYNC wave (an extra wave with no memory traffic of its own where the block has room for one, else wave 0) publishes
 // this member's episode and polls the group's flags, then the workgroup meets again.
@@ -264,7 +247,6 @@ __device__ __forceinline__ double xwave_reduce63(double v) {
 // The LDS tile of the n_e-wide mixing: [column k][lane][slot], slot 0 = the value, 1..D = the partials, padded to an
 // even count SL so that a lane's slots are one run of 16-byte pieces (ds_read/write_b128; lane stride 8*SL bytes is
 // conflict-free for SL = 2, 4, 6). One pass over k serves the value and every partial.
-template <int D> struct XTile { static constexpr int SL = D == 0 ? 1 : (D == 1 ? 2 : (D == 2 ? 4 : (D == 4 ? 6 : D + 2))); };
 template <int SL>
 __device__ __forceinline__ void xtile_store(double *t, const double *v) {      // v holds SL values
     if (SL == 1) { t[0] = v[0]; return; }
@@ -296,46 +278,43 @@ __device__ __forceinline__ void xtile_mix(const double *tl, const double *P, int
     }
 }
 
-// ================================ backward ====================================================
+// ================================ the Float64 sweeps ==========================================
+// One group (the XCD with id 0) runs them; the workgroups that landed elsewhere leave at once. They write the policy
+// sequence, the distribution path and the linearisation record the tangent sweeps — of either implementation — read.
 struct XBackArgs {
     Consts c;
     const double *ss_value;     // [G] terminal marginal value (BackwardIteration.jl:85)
     const double *xhh;          // [n_hh*P]
     const double *rho;          // [P] 1/(1+r_t)
-    const double *dxr, *dxw, *dxt;   // [P][Ntot] tangents of the household inputs
-    int Ntot, n0, N;            // row stride of dx*, first direction of this pass, directions in this pass
     XSync *sy;
-    double *st_s, *st_ds;       // state (see top)
-    double *pol;                // [P][G] policy sequence (written by group 0)
-    double *dpol;               // [P][groups][G][D] of this pass
-    int groups;                 // active groups of this pass = max(1, ceil(N / D))
+    double *st_s;               // [2][XG][G] knots (see top)
     int *err;                   // device error word of the context (knots / domain)
-    Record R;                   // R.ib != nullptr: group 0 also records the linearisation (s, kc, ib, A, B, u, v) for the tangent sweeps
+    Record R;                   // pol; s, kc, ib, A, B, u, v: the linearisation
 };
 
-template <int D, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
-    constexpr int DD = D ? D : 1;
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
-    constexpr int SL = XTile<D>::SL;
-    double *Vsh = xl;                                   // [ne][64][SL]
-    double *Pish = Vsh + (size_t)SL * ne * 64;          // [ne*ne]
+    double *Vsh = xl;                                   // [ne][64]
+    double *Pish = Vsh + (size_t)ne * 64;               // [ne*ne]
     double *ash = Pish + ne * ne;                       // [na]: the wealth grid (the bracket's grid values are a dependent load)
     double *xsh = ash + na;                             // [P][4]: r_t, w_t, tr_t, rho_t — a cold uniform load per period otherwise
     int *ctl = reinterpret_cast<int *>(xsh + 4 * (size_t)P);
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
-    if (x >= A.groups) return;                          // this XCD has no directions in this pass
+    if (x != 0) return;
     const int Sact = (na + XRW - 1) / XRW;              // members that own rows
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }   // the whole group agrees on S
     if (cW >= Sact) return;
-    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool syncw = wv >= ne;                        // see k_xtan_back
+    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
+    const int e = syncw ? 0 : wv;
     const int a = cW * XRW + lane;
-    const bool own = lane < XRW && a < na;
-    const bool leader = x == 0;
+    const bool own = !syncw && lane < XRW && a < na;
     const size_t pt = (size_t)e * na + (own ? a : 0);
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     for (int k = threadIdx.x; k < na; k += blockDim.x) ash[k] = c.a[k];
@@ -345,397 +324,195 @@ __global__ void __launch_bounds__(MAXT) k_xsweep_back(XBackArgs A) {
     Consts cl = c;                                      // what egm_Y sees: the same model, grid served from LDS
     cl.a = ash;
     const double ze = c.z[e], xa = c.a[own ? a : 0];
-    // this group's view of the ping-pong state: half h starts h*hs rows further on (no arrays indexed by h: they would
-    // live in scratch)
-    const size_t hs = (size_t)XG * G;
-    double *const sS = A.st_s + (size_t)x * G;
-    double *const sD = A.st_ds + (size_t)x * G * DD;
-    XRows<DD> rows;
-    rows.init(sD, (hs + G) * DD * 8);
-    const int nd = A.n0 + x * D;                        // first direction of this group in dx*
-    double *const myt = Vsh + ((size_t)e * 64 + lane) * SL;      // this lane's slots in the tile
-    // terminal value, zero partials (BackwardIteration.jl:85)
-    {
-        double v0[SL];
-#pragma unroll
-        for (int q = 0; q < SL; q++) v0[q] = 0.0;
-        v0[0] = own ? A.ss_value[pt] : 0.0;
-        xtile_store<SL>(myt, v0);
-    }
+    const size_t hs = (size_t)XG * G;                   // the other half of the ping-pong state
+    double *const sS = A.st_s;
+    if (!syncw) Vsh[e * 64 + lane] = own ? A.ss_value[pt] : 0.0;      // terminal value (BackwardIteration.jl:85)
     __syncthreads();
-    int cur = 0, guess = -1;
+    int guess = -1;
     unsigned episode = 0;
-    const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact - 1) ? 1 : -1);
-    (void)son;
-    // X half of period tx from V_{tx+1}, dV_{tx+1} in LDS (KrusellSmith.jl:59-62; same expressions as egm_X): the knots
-    // s_tx and their partials -> state[buf]
-    auto xhalf = [&](int tx, int buf) {
-        const double w1 = xsh[4 * tx + 1], tr1 = xsh[4 * tx + 2];
-        if (!own) return;
-        double mx[1 + D];                                  // E and dE_k: one pass over the tile
-        xtile_mix<SL, 1 + D>(Vsh + (size_t)lane * SL, Pish + e, ne, ne, mx);
-        const double E = mx[0];
-        const double bE = E * c.beta;
-        const double ex = -1.0 / c.gamma;
-        if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);
-        const double cm = pow_crra(bE, ex);
-        const double rho = xsh[4 * tx + 3];                // 1/(1+r_tx), once per period (k_xrho), not once per thread
-        const double s1 = rho * ((cm - (w1 * ze + tr1)) + xa);
-        const double kc = rho * (c.beta * ex * (cm / bE));
-        sS[(size_t)buf * hs + pt] = s1;
-        if (leader && A.R.ib) { A.R.s[(size_t)tx * G + pt] = s1; A.R.kc[(size_t)tx * G + pt] = kc; }
-        if (D > 0) {
-            double ds[DD];
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const double dE = mx[1 + k];
-                const bool on = x * D + k < A.N;
-                const size_t ix = (size_t)tx * A.Ntot + nd + k;
-                const double dr1 = on ? A.dxr[ix] : 0.0, dw1 = on ? A.dxw[ix] : 0.0;
-                const double dt1 = (on && c.n_hh > 2) ? A.dxt[ix] : 0.0;
-                ds[k] = kc * dE - rho * ((ze * dw1 + dt1) + s1 * dr1);
-            }
-            xstore_row<DD>(sD + ((size_t)buf * hs + pt) * DD, ds);
-        }
-    };
     // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0), one group barrier after every X
     for (int i = 0; i <= P; i++) {
         if (i > 0) {
-            // ---- Y half of period t (KrusellSmith.jl:66-80 under Dual): bracket gather -> policy and its partials,
-            //      marginal value and its partials -> LDS
-            const int t = P - i;
-            cur = (i - 1) & 1;
-            XSTAMP(0, son, t, 0);
-            const double r = xsh[4 * t], w = xsh[4 * t + 1], tr = xsh[4 * t + 2];
-            double V = 0.0, dV[DD];
-#pragma unroll
-            for (int k = 0; k < DD; k++) dV[k] = 0.0;
+            // ---- Y half of period t (KrusellSmith.jl:66-80): bracket search in the L2-resident knots -> policy, marginal value -> LDS
+            const int t = P - i, cur = (i - 1) & 1;
+            double V = 0.0;
             if (own) {
                 XKnots kn;
                 kn.preload(sS + (size_t)cur * hs + (size_t)e * na, a, na, guess);
-                const size_t rb = (size_t)cur * hs + (size_t)e * na;
-                double d0[DD], d1[DD];
-#pragma unroll
-                for (int k = 0; k < DD; k++) d0[k] = d1[k] = 0.0;
-                const int pg = guess < 0 ? -1 : (guess < na - 1 ? guess : na - 2);
-                if (D > 0 && pg >= 0) {          // speculative: brackets move by a few knots per period
-                    rows.load(rb + pg, d0);
-                    rows.load(rb + pg + 1, d1);
-                }
-                const YOut o = egm_Y(cl, kn, a, e, r, w, tr, A.err, t, guess);
-                XSTAMP(0, son, t, 1);
-                if (D > 0 && o.ib != pg && (o.A != 0.0 || o.B != 0.0)) {
-                    rows.load(rb + o.ib, d0);
-                    rows.load(rb + o.ib + 1, d1);
-                }
+                const YOut o = egm_Y(cl, kn, a, e, xsh[4 * t], xsh[4 * t + 1], xsh[4 * t + 2], A.err, t, guess);
                 guess = o.ib;
                 V = o.V;
-                if (leader) {
-                    A.pol[(size_t)t * G + pt] = o.g;
-                    if (A.R.ib) {
-                        const size_t ro = (size_t)t * G + pt;
-                        A.R.ib[ro] = o.ib; A.R.A[ro] = o.A; A.R.B[ro] = o.B; A.R.u[ro] = o.u; A.R.v[ro] = o.v;
-                    }
-                }
-                if (D > 0) {
-                    double dg[DD];
-#pragma unroll
-                    for (int k = 0; k < D; k++) {
-                        const bool on = x * D + k < A.N;
-                        const size_t ix = (size_t)t * A.Ntot + nd + k;
-                        const double dr = on ? A.dxr[ix] : 0.0, dw = on ? A.dxw[ix] : 0.0;
-                        const double dtr = (on && c.n_hh > 2) ? A.dxt[ix] : 0.0;
-                        dg[k] = o.A * d0[k] + o.B * d1[k];
-                        dV[k] = o.u * dr + o.v * ((xa * dr + (ze * dw + dtr)) - dg[k]);
-                    }
-                    xstore_row<DD>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * DD, dg);
-                }
+                const size_t ro = (size_t)t * G + pt;
+                A.R.pol[ro] = o.g; A.R.ib[ro] = o.ib; A.R.A[ro] = o.A; A.R.B[ro] = o.B; A.R.u[ro] = o.u; A.R.v[ro] = o.v;
             }
-            {
-                double vs[SL];
-#pragma unroll
-                for (int q = 0; q < SL; q++) vs[q] = 0.0;
-                vs[0] = V;
-#pragma unroll
-                for (int k = 0; k < D; k++) vs[1 + k] = dV[k];
-                xtile_store<SL>(myt, vs);
-            }
-            XSTAMP(0, son, t, 2);
+            if (!syncw) Vsh[e * 64 + lane] = V;
             xlds_barrier();
-            XSTAMP(0, son, t, 3);
         }
         if (i < P) {
-            xhalf(P - 1 - i, i & 1);
-            XSTAMP(0, son, P - i, 4);
+            // ---- X half of period tx from V_{tx+1} in LDS (KrusellSmith.jl:59-62; same expressions as egm_X): the knots s_tx -> state[i & 1]
+            const int tx = P - 1 - i;
+            if (own) {
+                double E;
+                xtile_mix<1, 1>(Vsh + lane, Pish + e, ne, ne, &E);
+                const double bE = E * c.beta;
+                const double ex = -1.0 / c.gamma;
+                if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);
+                const double cm = pow_crra(bE, ex);
+                const double rho = xsh[4 * tx + 3];             // 1/(1+r_tx), once per period (k_xrho), not once per thread
+                const double s1 = rho * ((cm - (xsh[4 * tx + 1] * ze + xsh[4 * tx + 2])) + xa);
+                const double kc = rho * (c.beta * ex * (cm / bE));
+                sS[(size_t)(i & 1) * hs + pt] = s1;
+                A.R.s[(size_t)tx * G + pt] = s1; A.R.kc[(size_t)tx * G + pt] = kc;
+            }
             episode++;
-            xbarrier(A.sy, x, cW, Sact, episode, 0, son, P - i);
+            xbar_arrive(!syncw);
+            xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
         }
     }
 }
 
-// ================================ forward =====================================================
 struct XFwdArgs {
     Consts c;
-    Record R;                   // pol, seg, clo (k_lottery ran on the policy sequence)
+    Record R;                   // pol, seg, clo, lw, ig (k_lottery ran on the policy sequence); lwg and Dseq rows 1..P are written here
     const double *D0;           // [G] initial distribution (ForwardIteration.jl:293)
     XSync *sy;
-    double *st_D, *st_dD;       // state incl. the virtual rows
-    const double *dpol;         // [P][groups][G][D] of this pass
-    int groups, N;
-    double *Dseq;               // [P+1][G] distribution path (group 0 writes rows 1..P; row 0 of a column lacks the virtual mass)
-    double *Dvirt;              // [P][n_e][64] that virtual mass, per member (added to row 0 by k_xfix_D)
-    double *aggpart;            // [P][Sact*n_e]            Float64 aggregate partials (group 0)
-    double *daggpart;           // [P][Sact*n_e][XG*D]      partials of the aggregate
-    int record;                 // group 0 also writes R.lwg for the tangent sweeps
+    double *st_D;               // [2][XG][G + 64*n_e] state incl. the virtual rows
+    double *Dvirt;              // [P][n_e][64] the mass kept on the virtual rows, per member (added to row 0 by k_xfix_D)
+    double *aggpart;            // [P][Sact*n_e] aggregate partials
 };
 
-template <int D, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_xsweep_fwd(XFwdArgs A) {
-    constexpr int DD = D ? D : 1;
-    constexpr int SL = XTile<D>::SL;
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const Record &R = A.R;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     const int GV = G + 64 * ne;
-    double *tile = xl;                                  // [ne][64][SL]
-    double *Pish = tile + (size_t)SL * ne * 64;
+    double *tile = xl;                                  // [ne][64]
+    double *Pish = tile + (size_t)ne * 64;
     int *closh = reinterpret_cast<int *>(Pish + ne * ne);      // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
     int *ctl = closh + (size_t)P * ne;
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
-    if (x >= A.groups) return;
+    if (x != 0) return;
     const int Sact = (na + XRW - 1) / XRW;
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
     for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // wave n_e (when the block has one) is the RUN-AHEAD wave: it only touches next period's record and policy-partial
-    // lines of this member's rows, so that every compute wave of the XCD finds them in L2 (its loads wait on its own
-    // counter, not on the compute waves')
-    const bool runahead = wv >= ne;
-    const int e = runahead ? 0 : wv;
-    const int r0 = cW * XRW;
-    const int r = r0 + lane;
-    const bool own = !runahead && lane < XRW && r < na;
-    const bool virt = !runahead && lane == 63;          // this wave's virtual row: slot cW of column e
-    const bool leader = x == 0;
+    const bool syncw = wv >= ne;
+    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
+    const int e = syncw ? 0 : wv;
+    const int r0 = cW * XRW, r = r0 + lane;
+    const bool own = !syncw && lane < XRW && r < na;
+    const bool virt = !syncw && lane == 63;             // this wave's virtual row: slot cW of column e
     const size_t pt = (size_t)e * na + (own ? r : 0);
     const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;      // where this lane's state lives (virtual lanes: the tail)
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
-    const size_t hs = (size_t)XG * GV;                  // rows between the two halves of the ping-pong state
-    double *const sP = A.st_D + (size_t)x * GV;
-    double *const sT = A.st_dD + (size_t)x * GV * DD;
-    XRows<DD> rows;
-    rows.init(sT, (hs + GV) * DD * 8);
-    double *const myt = tile + ((size_t)e * 64 + lane) * SL;
+    const size_t hs = (size_t)XG * GV;                  // the other half of the ping-pong state
+    double *const sP = A.st_D;
     // lottery geometry of this lane's row as a TARGET: sources of its first segment have bracket r-1, of its second r
     const double a_m = c.a[own && r > 0 ? r - 1 : 0], a_0 = c.a[own ? r : 0], a_p = c.a[own && r + 1 < na ? r + 1 : na - 1];
     const double a_top = c.a[na - 1];
-    // D_0 and zero partials into state[0] (ForwardIteration.jl:293: the initial distribution carries no partials)
-    {
-        double z[DD];
-#pragma unroll
-        for (int k = 0; k < DD; k++) z[k] = 0.0;
-        if (own || virt) {
-            sP[slot] = own ? A.D0[pt] : 0.0;
-            if (D > 0) xstore_row<DD>(sT + slot * DD, z);
-        }
-    }
+    if (own || virt) sP[slot] = own ? A.D0[pt] : 0.0;   // D_0 into state[0]
+    // this lane's own-row record of the period about to be processed, fetched between the halves of the previous barrier
+    int4 sg = make_int4(0, 0, 0, 0);
+    double polr = 0.0, lwr = 0.0, igr = 0.0;
+    auto prefetch = [&](int t) {
+        const size_t base = (size_t)t * G + (size_t)e * na;
+        if (own) { sg = R.seg[base + r]; polr = R.pol[base + r]; lwr = R.lw[base + r]; igr = R.ig[base + r]; }
+        else if (virt) polr = R.pol[base];              // a virtual row sits at the first grid point
+    };
     unsigned episode = 1;
-    xbarrier(A.sy, x, cW, Sact, episode);
+    xbar_arrive(!syncw);
+    prefetch(0);
+    xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
     int cur = 0;
-    const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact - 1) ? 1 : -1);
-    (void)son;
     bool vnz = false;                                   // the virtual rows may hold mass: some column was clamped last period
                                                         // (the exogenous transition spreads it over every column's virtual rows)
-    constexpr int NRA = MAXT == 768 ? 11 : 15;          // columns a block with a run-ahead wave can have
-    int touched[NRA], sink_i = 0;                       // the run-ahead wave's loads, consumed a period later
-#pragma unroll
-    for (int ee = 0; ee < NRA; ee++) touched[ee] = 0;
     for (int t = 0; t < P; t++) {
-        XSTAMP(1, son, t, 0);
         const size_t base = (size_t)t * G + (size_t)e * na;
         const size_t hb = (size_t)cur * hs;             // this period reads half `cur`
-        const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;      // row index into dpol
         int clo = 0;
         bool vnz_next = false;                          // some column is clamped this period (every wave reads all n_e counts)
         for (int k = 0; k < ne; k++) vnz_next = vnz_next || closh[t * ne + k] > 0;
-        double accD = 0.0, acc[DD], polr = 0.0, dpr[DD];
-#pragma unroll
-        for (int k = 0; k < DD; k++) acc[k] = dpr[k] = 0.0;
-        if (runahead) {
-            // consume what was touched one period ago (long landed: no wait), then touch period t+1: per column one
-            // wave-instruction, a dword every 64 bytes of this member's seg (16 lanes), pol (8) and dpol (8*D) runs
-#pragma unroll
-            for (int ee = 0; ee < NRA; ee++) sink_i ^= touched[ee];
-            if (t + 1 < P) {
-                const int rows_here = min(XRW, na - r0);
-                const char *p = nullptr;
-                int off = 0, len = 0;
-                if (lane < 16) { off = lane * 64; len = rows_here * 16; }
-                else if (lane < 24) { off = (lane - 16) * 64; len = rows_here * 8; }
-                else if (lane < 24 + 8 * D) { off = (lane - 24) * 64; len = rows_here * 8 * D; }
-#pragma unroll
-                for (int ee = 0; ee < NRA; ee++) {
-                    if (ee < ne) {
-                        const size_t el = (size_t)(t + 1) * G + (size_t)ee * na + r0;
-                        if (lane < 16) p = reinterpret_cast<const char *>(R.seg + el);
-                        else if (lane < 24) p = reinterpret_cast<const char *>(R.pol + el);
-                        else p = reinterpret_cast<const char *>(A.dpol + (((size_t)(t + 1) * A.groups + x) * G + (size_t)ee * na + r0) * DD);
-                        if (off < len) touched[ee] = *reinterpret_cast<const int *>(p + off);
-                    }
-                }
-            }
-        } else {
+        double accD = 0.0;
+        if (!syncw) {
             clo = min(max(closh[t * ne + e], 0), na);
             const double *Dp = sP + hb + (size_t)e * na;
             // the mass that sits on the virtual rows of this column (needed by the targets of source 0 when row 0 is not
             // clamped, and folded into D_{t-1}[0] there): summed by the wave, member order fixed
-            double vD = 0.0, vT[DD];
-#pragma unroll
-            for (int k = 0; k < DD; k++) vT[k] = 0.0;
+            double vD = 0.0;
             if (vnz && clo == 0) {
-                if (lane < Sact) {
-                    const size_t vs = (size_t)G + (size_t)e * 64 + lane;
-                    vD = xld(sP + hb + vs);
-                    if (D > 0) rows.load(hb + vs, vT);
-                }
+                if (lane < Sact) vD = xld(sP + hb + (size_t)G + (size_t)e * 64 + lane);
                 vD = xwave_sum(vD);
-#pragma unroll
-                for (int k = 0; k < D; k++) vT[k] = xwave_sum(vT[k]);
             }
-            if (own && leader && A.record) {      // what the tangent sweeps read per SOURCE: {w, ig * D_{t-1}} (k_lottery's w and ig)
+            if (own) {      // what the tangent sweeps read per SOURCE: {w, ig * D_{t-1}} (k_lottery's w and ig)
                 double Dfull = xld(Dp + r);
                 if (r == 0 && clo == 0) Dfull += vD;
-                R.lwg[base + r] = make_double2(R.lw[base + r], R.ig[base + r] * Dfull);
-            }
-            if (own) {
-                int4 sg = R.seg[base + r];
-                sg.x = max(sg.x, 0); sg.z = min(sg.z, na);        // (a record that is not a lottery must not turn into a long loop)
-                polr = R.pol[base + r];
-                if (D > 0) xload_row_plain<DD>(A.dpol + (dbase + r) * DD, dpr);
+                R.lwg[base + r] = make_double2(lwr, igr * Dfull);
+                const int s0 = max(sg.x, 0), s2 = min(sg.z, na);      // (a record that is not a lottery must not turn into a long loop)
                 // sources two at a time: both sources' loads are in flight before either is used
-                for (int j0 = sg.x; j0 < sg.z; j0 += 2) {
-                    double pj[2], Dj[2], dDj[2][DD], dpj[2][DD];
+                for (int j0 = s0; j0 < s2; j0 += 2) {
+                    double pj[2], Dj[2];
                     bool on[2];
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int j = j0 + u;
-                        on[u] = j < sg.z;
+                        on[u] = j < s2;
                         pj[u] = 0.0; Dj[u] = 0.0;
-#pragma unroll
-                        for (int k = 0; k < DD; k++) dDj[u][k] = dpj[u][k] = 0.0;
-                        if (on[u]) {
-                            pj[u] = R.pol[base + j];
-                            Dj[u] = xld(Dp + j);
-                            if (D > 0) {
-                                rows.load(hb + (size_t)e * na + j, dDj[u]);
-                                xload_row_plain<DD>(A.dpol + (dbase + j) * DD, dpj[u]);
-                            }
-                        }
+                        if (on[u]) { pj[u] = R.pol[base + j]; Dj[u] = xld(Dp + j); }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int j = j0 + u;
                         if (!on[u]) continue;
                         const bool first = j < sg.y;                      // source's upper target is this row
-                        if (j == 0) {            // (then clo == 0) row 0's virtual rows follow row 0's interior lottery
-                            Dj[u] += vD;
-#pragma unroll
-                            for (int k = 0; k < D; k++) dDj[u][k] += vT[k];
-                        }
+                        if (j == 0) Dj[u] += vD;     // (then clo == 0) row 0's virtual rows follow row 0's interior lottery
                         // Young lottery of source j (ForwardIteration.jl:59-73; same expressions as k_lottery)
                         const double al = first ? a_m : a_0, gap = first ? a_0 - a_m : a_p - a_0;
-                        double wj = (pj[u] - al) / gap, ig = 1.0 / gap;
-                        if (pj[u] > a_top) { wj = 1.0; ig = 0.0; }        // all mass on the last point (:59-63)
-                        const double gD = ig * Dj[u], wt = first ? wj : 1.0 - wj;
-                        accD += wt * Dj[u];
-#pragma unroll
-                        for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[u][k] + gD * dpj[u][k]) : (wt * dDj[u][k] - gD * dpj[u][k]);
+                        double wj = (pj[u] - al) / gap;
+                        if (pj[u] > a_top) wj = 1.0;                      // all mass on the last point (:59-63)
+                        accD += (first ? wj : 1.0 - wj) * Dj[u];
                     }
                 }
             }
-            XSTAMP(1, son, t, 1);
-            // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one and no weight
-            // partial. Each member sums ITS rows of the clamped prefix into its virtual row (never combined: everything
-            // downstream is linear); while row 0 itself is clamped the old virtual row is carried along.
+            // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one. Each member sums
+            // ITS rows of the clamped prefix into its virtual row (never combined: everything downstream is linear); while
+            // row 0 itself is clamped the old virtual row is carried along.
             {
-                double cD = 0.0, cT[DD];
-#pragma unroll
-                for (int k = 0; k < DD; k++) cT[k] = 0.0;
-                if (own && r < clo) {
-                    cD = xld(Dp + r);
-                    if (D > 0) rows.load(hb + (size_t)e * na + r, cT);
-                }
-                if (virt && clo > 0 && vnz) {
-                    cD = xld(sP + hb + slot);
-                    if (D > 0) rows.load(hb + slot, cT);
-                }
-                if (clo > r0) {                     // wave-uniform: some of this member's rows are clamped (lane 63 takes the sum)
-                    cD = xwave_reduce63(cD);
-#pragma unroll
-                    for (int k = 0; k < D; k++) cT[k] = xwave_reduce63(cT[k]);
-                }
-                if (virt) {
-                    accD = cD;
-#pragma unroll
-                    for (int k = 0; k < D; k++) acc[k] = cT[k];
-                }
+                double cD = 0.0;
+                if (own && r < clo) cD = xld(Dp + r);
+                if (virt && clo > 0 && vnz) cD = xld(sP + hb + slot);
+                if (clo > r0) cD = xwave_reduce63(cD);      // wave-uniform: some of this member's rows are clamped (lane 63 takes the sum)
+                if (virt) accD = cD;
             }
-            XSTAMP(1, son, t, 2);
-            double vs[SL];
-#pragma unroll
-            for (int q = 0; q < SL; q++) vs[q] = 0.0;
-            vs[0] = accD;
-#pragma unroll
-            for (int k = 0; k < D; k++) vs[1 + k] = acc[k];
-            xtile_store<SL>(myt, vs);
+            tile[e * 64 + lane] = accD;
         }
         xlds_barrier();
         vnz = vnz_next;
-        XSTAMP(1, son, t, 3);
         const int nxt = cur ^ 1;
-        if (!runahead) {
-            // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99), partials alike
-            double mx[1 + D];
-            xtile_mix<SL, 1 + D>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
-            const double Dn = mx[0];
+        if (!syncw) {
+            // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99)
+            double Dn;
+            xtile_mix<1, 1>(tile + lane, Pish + ne * e, 1, ne, &Dn);
             if (own || virt) {
                 sP[(size_t)nxt * hs + slot] = Dn;
-                if (D > 0) xstore_row<DD>(sT + ((size_t)nxt * hs + slot) * DD, mx + 1);
-                if (leader) {
-                    if (own) A.Dseq[(size_t)(t + 1) * G + pt] = Dn;
-                    else A.Dvirt[((size_t)t * ne + e) * 64 + cW] = Dn;
-                }
+                if (own) R.Dseq[(size_t)(t + 1) * G + pt] = Dn;
+                else A.Dvirt[((size_t)t * ne + e) * 64 + cW] = Dn;
             }
-            XSTAMP(1, son, t, 4);
-            // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307): sum(pol_t * D_t) and its partials;
-            // a virtual row sits at the first grid point: it carries row 0's policy and policy partials
-            double pol_here = polr, dp_here[DD];
-#pragma unroll
-            for (int k = 0; k < DD; k++) dp_here[k] = dpr[k];
-            if (virt) {
-                pol_here = R.pol[base];
-                if (D > 0) xload_row_plain<DD>(A.dpol + dbase * DD, dp_here);
-            }
-            const bool live = own || virt;
-            const double pD = xwave_reduce63(live ? pol_here * Dn : 0.0);
-            const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
-            if (leader && lane == 63) A.aggpart[pb] = pD;
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const double pd = xwave_reduce63(live ? (pol_here * mx[1 + k] + dp_here[k] * Dn) : 0.0);
-                if (lane == 63) A.daggpart[pb * (size_t)(XG * DD) + x * D + k] = pd;
-            }
+            // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307): sum(pol_t * D_t); a virtual row
+            // carries row 0's policy
+            const double pD = xwave_reduce63((own || virt) ? polr * Dn : 0.0);
+            if (lane == 63) A.aggpart[(size_t)t * Sact * ne + (size_t)cW * ne + e] = pD;
         }
         cur = nxt;
         episode++;
-        XSTAMP(1, son, t, 5);
-        xbarrier(A.sy, x, cW, Sact, episode, 1, son, t, !runahead);
+        xbar_arrive(!syncw);
+        if (t + 1 < P) prefetch(t + 1);
+        xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
     }
-    if (runahead && sink_i == 0x7f123457) A.Dvirt[0] = 1.0;     // (practically never true: the touches above must not be optimised away)
 }
 
 // ================================ tangent-only sweeps at a recorded primal ===================================
@@ -1019,7 +796,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                 }
             }
             XSTAMP(1, son, t, 1);
-            {   // the mass point (see k_xsweep_fwd)
+            {   // the mass point (see k_xprimal_fwd)
                 double cT[D];
 #pragma unroll
                 for (int k = 0; k < D; k++) cT[k] = 0.0;
