@@ -75,6 +75,8 @@ struct XWork {
     XSync *sync = nullptr;          // [2 * XPASS_MAX]: backward and forward sweep of every pass
     double *st_s = nullptr, *st_ds = nullptr, *st_D = nullptr, *st_dD = nullptr;
     double *Dvirt = nullptr, *aggpart = nullptr, *rho = nullptr;
+    int *srcB = nullptr, *srcF = nullptr;     // [P][Sact] source-member ranges of the tangent sweeps at the recorded primal
+    bool src_valid = false;
     std::list<XTan> tans;           // most recently used first
     int last_passes = 0;            // sync blocks the last call used (their status words are checked)
 };
@@ -107,7 +109,7 @@ struct hank_ctx {
     // the persistent sweeps are supported): each entry point takes the faster of the two for its shape — see sched_*
     int schedule = 2;
     int last_tan = 0;              // which implementation ran the last tangent sweep (0 launches, 1 persistent): hank_get_dpolicy_seq
-    int xjvp_max = 32;             // auto: batches up to this width take the persistent tangent sweeps (measured crossover)
+    int xjvp_max = 64;             // auto: batches up to this width take the persistent tangent sweeps (measured crossover)
     XWork xw;
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // see hank_stats
@@ -435,7 +437,7 @@ static void x_free(hank_ctx *ctx) {
     X.tans.clear();
     ctx->xcur = nullptr;
     (void)hipFree(X.sync); (void)hipFree(X.st_s); (void)hipFree(X.st_ds); (void)hipFree(X.st_D); (void)hipFree(X.st_dD);
-    (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart); (void)hipFree(X.rho);
+    (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart); (void)hipFree(X.rho); (void)hipFree(X.srcB); (void)hipFree(X.srcF);
     X = XWork();
 }
 
@@ -459,6 +461,8 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.Dvirt, P * c.n_e * 64));
     HIPC(ctx, dmalloc(&X.aggpart, P * (size_t)X.Sact * c.n_e));
     HIPC(ctx, dmalloc(&X.rho, P));
+    HIPC(ctx, dmalloc(&X.srcB, P * X.Sact));
+    HIPC(ctx, dmalloc(&X.srcF, P * X.Sact));
     HIPC(ctx, hipMemset(X.Dvirt, 0, sizeof(double) * P * c.n_e * 64));
     X.ready = true;
     return HANK_OK;
@@ -582,6 +586,7 @@ static int x_run_primal(hank_ctx *ctx) {
     ctx->ev_valid[0] = ctx->ev_valid[1] = true;
     ctx->ev_valid[2] = ctx->ev_valid[3] = ctx->ev_valid[4] = ctx->ev_valid[5] = false;
     ctx->primal_done = true;
+    X.src_valid = false;
     for (XTan &t : X.tans) t.valid = false;
     ctx->xcur = nullptr;
     return HANK_OK;
@@ -600,6 +605,13 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     HIPC(ctx, hipMemsetAsync(X.sync + 2, 0, sizeof(XSync) * 2 * np, s));
     hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);     // (the primal may have been recorded by the launches)
+    if (!X.src_valid) {      // once per recorded primal: which members each member's gathers read, period by period
+        hipLaunchKernelGGL(k_xsrc_back, dim3((unsigned)P, X.Sact), dim3(256), 0, s, c, ctx->R, X.Sact, X.srcB);
+        hipLaunchKernelGGL(k_xsrc_fwd, dim3((unsigned)P, X.Sact), dim3(256), 0, s, c, ctx->R, X.Sact, X.srcF);
+        X.src_valid = true;
+    }
+    const char *ng = getenv("HANK_XNEIGH");      // dev knob: 0 = every period waits for every member
+    const bool neigh = !(ng && atoi(ng) == 0);
     const dim3 grd(X.grid);
     // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
     const char *swv = getenv("HANK_XSYNCWAVE");
@@ -607,14 +619,15 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     const dim3 blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkF = blk;
     XTanBackArgs ab{};
     ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st_ds = X.st_ds;
+    ab.src = neigh ? X.srcB : nullptr;
     XTanFwdArgs af{};
-    af.c = c; af.R = ctx->R; af.st_dD = X.st_dD; af.Dvirt = X.Dvirt; af.daggpart = w->daggpart;
+    af.c = c; af.R = ctx->R; af.st_dD = X.st_dD; af.Dvirt = X.Dvirt; af.daggpart = w->daggpart; af.src = neigh ? X.srcF : nullptr;
     HIPC(ctx, hipEventRecord(ctx->ev[3], s));
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
         const int SLt = ps.D == 4 ? 6 : ps.D;      // XTileT<D>::SL
-        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + P + 3 * P * ps.D) + 64;
+        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + P + 3 * P * ps.D) + sizeof(int) * P + 64;
         if (X.maxt == 768) x_launch_tan<768>(ps.D, true, grd, blk, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, true, grd, blk, lds, s, ab, af);
     }
@@ -625,7 +638,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
         const XPass &ps = w->passes[p];
         af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.N = ps.N; af.dpol = w->dpol + ps.dpol_off;
         const int SLt = ps.D == 4 ? 6 : ps.D;
-        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * P * c.n_e + 64;
+        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * (P * c.n_e + P) + 64;
         if (X.maxt == 768) x_launch_tan<768>(ps.D, false, grd, blkF, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, false, grd, blkF, lds, s, ab, af);
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
@@ -740,7 +753,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
     HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_stream, hipEventDisableTiming));
     // schedule (measured on MI355X): "auto" wherever the grid fits one 63-row slab per CU of an XCD —
-    // the Float64 sweeps alone (hank_primal) and narrow tangent batches at a recorded primal (hank_jvp, N <= 32) run as
+    // the Float64 sweeps alone (hank_primal) and narrow tangent batches at a recorded primal (hank_jvp, N <= 64) run as
     // XCD-local persistent sweeps, the dual pass (hank_primal_jvp) and wide batches as per-period launches; both
     // read and write the same record. HANK_SCHEDULE=launch|xcd forces one implementation for everything (A-B, tests).
     const char *se = getenv("HANK_SCHEDULE");
@@ -839,6 +852,7 @@ static int run_primal(hank_ctx *ctx, double *d_agg_out) {
     ctx->ev_valid[0] = ctx->ev_valid[1] = true;
     ctx->ev_valid[4] = ctx->ev_valid[5] = false;
     ctx->primal_done = true;
+    ctx->xw.src_valid = false;
     for (TanWork &t : ctx->tws) t.valid = false;
     return HANK_OK;
 }
@@ -1026,6 +1040,7 @@ static int run_fused(hank_ctx *ctx) {
     ctx->ev_valid[4] = ctx->ev_valid[5] = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
     ctx->primal_done = true;
+    ctx->xw.src_valid = false;
     for (TanWork &t : ctx->tws) t.valid = false;
     w.valid = true;
     ctx->last_tan = 0;

@@ -184,6 +184,28 @@ __device__ __forceinline__ void xbar_wait(XSync *sy, int x, int c, int members, 
     xlds_barrier();
 }
 
+// The tangent sweeps split the barrier further. A member's period t needs the state rows of FEW other members (the
+// brackets / lottery segments of its 63 rows: recorded by the primal, so the range of members is known in advance), and
+// it may overwrite a state half only when EVERY member is done reading it. So: (1) before a period's gathers wait only
+// for the source members' episode; (2) before the period's state stores — a whole gather-and-mix phase later — check that
+// all members have published the previous episode; (3) publish after the stores have drained, and wait for nobody.
+// Arrival skew up to the length of the first phase disappears from the critical path. xpoll: one wave, bounded.
+__device__ __forceinline__ void xpoll(XSync *sy, int x, int lo, int hi, unsigned need) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spins = 0;; spins++) {
+        const unsigned f = (lane >= lo && lane <= hi) ? xldu(&sy->flag[x][lane][0]) : need;
+        if (__all((int)(f - need) >= 0)) break;
+        if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
+            if (lane == 0) xfail(sy, XERR_TIMEOUT, x);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void xpublish(XSync *sy, int x, int c, unsigned episode) {
+    if ((threadIdx.x & 63) == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c][0]) = episode;
+}
+
 // knots of one column, read from the L2-resident state. Everything egm_Y is going to look at in the usual case — the
 // row's own knot and its lower neighbour (sortedness check), the column's two end knots (flat extrapolation) and the
 // four knots around the guessed bracket — is fetched in ONE batch of independent loads up front: behind the branches
@@ -535,6 +557,7 @@ struct XTanBackArgs {
     double *st_ds;              // [2][XG][G][D]
     double *dpol;               // [P][groups][G][D]
     int groups;
+    const int *src;             // [P][members] lo | hi << 8: the members whose rows period t's gathers of member c read (k_xsrc_back); null = all
 };
 
 template <int D, int MAXT>
@@ -548,7 +571,8 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     double *Pish = tile + (size_t)SL * ne * 64;
     double *rhosh = Pish + ne * ne;                     // [P]
     double *dxsh = rhosh + P;                           // [P][3][D]: this group's dr, dw, dtr (a cold uniform load per period otherwise)
-    int *ctl = reinterpret_cast<int *>(dxsh + (size_t)P * 3 * D);
+    int *srcsh = reinterpret_cast<int *>(dxsh + (size_t)P * 3 * D);      // [P]: this member's source ranges
+    int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
@@ -557,6 +581,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
     for (int k = threadIdx.x; k < P; k += blockDim.x) rhosh[k] = A.rho[k];
+    for (int k = threadIdx.x; k < P; k += blockDim.x) srcsh[k] = A.src ? A.src[(size_t)k * Sact + cW] : ((Sact - 1) << 8);
     for (int k = threadIdx.x; k < P * D; k += blockDim.x) {
         const int t_ = k / D, d_ = k - t_ * D;
         const bool on = x * D + d_ < A.N;
@@ -591,15 +616,13 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     int ibY = 0;
     double cA = 0.0, cB = 0.0, cu = 0.0, cv = 0.0, ck = 0.0, cs = 0.0;
     if (own) { ck = R.kc[(size_t)(P - 1) * G + pt]; cs = R.s[(size_t)(P - 1) * G + pt]; }
-    unsigned episode = 0;
-    const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact - 1) ? 1 : -1);
-    (void)son;
-    // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0), one group barrier after every X
+    // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0); member c publishes episode i+1 when the stores of trip i have drained
     for (int i = 0; i <= P; i++) {
-        XSTAMP(0, son, P - i, 0);
         if (i > 0) {
             // ---- Y-tangent of period t: dg = A ds[ib] + B ds[ib+1]; dV = u dr + v ((a dr + z dw + dtr) - dg)
             const int t = P - i, cur = (i - 1) & 1;
+            if (sync_duty) xpoll(A.sy, x, srcsh[t] & 255, srcsh[t] >> 8, (unsigned)i);    // the members this period gathers from have published trip i-1
+            xlds_barrier();
             double dV[D];
 #pragma unroll
             for (int k = 0; k < D; k++) dV[k] = 0.0;
@@ -620,14 +643,9 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                 }
                 xstore_row<D>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * D, dg);
             }
-            XSTAMP(0, son, t, 1);
             if (!syncw) xtile_store_n<SL, D>(myt, dV);
-            XSTAMP(0, son, t, 2);
-            XSTAMPW(0, son, t, 5, ne / 2);
-            XSTAMPW(0, son, t, 6, ne - 1);
-            XSTAMPW(0, son, t, 7, ne);
+            if (sync_duty) xpoll(A.sy, x, 0, Sact - 1, (unsigned)i);      // EVERY member is done reading the half the X half overwrites
             xlds_barrier();
-            XSTAMP(0, son, t, 3);
         }
         if (i < P) {
             // ---- X-tangent of period tx: ds = kc dE - rho ((z dw + dtr) + s dr)
@@ -643,17 +661,13 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                 }
                 xstore_row<D>(sD + ((size_t)(i & 1) * hs + pt) * D, ds);
             }
-            episode++;
-            XSTAMP(0, son, P - i, 4);
-            xbar_arrive(!syncw);
-            XSTAMP(0, son, P - i, 9);
-            if (own) {      // the record the next trip needs: Y of period tx, X of period tx - 1
+            xbar_arrive(!syncw);                                         // this member's stores have reached L2
+            if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(i + 1));
+            if (own) {      // the record the next trip needs (Y of period tx, X of period tx - 1): in flight while the others arrive
                 const size_t ro = (size_t)tx * G + pt;
                 ibY = R.ib[ro]; cA = R.A[ro]; cB = R.B[ro]; cu = R.u[ro]; cv = R.v[ro];
                 if (tx > 0) { ck = R.kc[ro - G]; cs = R.s[ro - G]; }
             }
-            xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
-            XSTAMP(0, son, P - i, 11);
         }
     }
 }
@@ -667,6 +681,7 @@ struct XTanFwdArgs {
     int groups, N;
     const double *Dvirt;        // [P][n_e][64] the primal's virtual mass
     double *daggpart;           // [P][Sact*n_e][XG*D]
+    const int *src;             // [P][members] lo | hi << 8 (k_xsrc_fwd); null = all
 };
 
 template <int D, int MAXT>
@@ -680,7 +695,8 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     double *tile = xl;
     double *Pish = tile + (size_t)SL * ne * 64;
     int *closh = reinterpret_cast<int *>(Pish + ne * ne);      // [P][ne]
-    int *ctl = closh + (size_t)P * ne;
+    int *srcsh = closh + (size_t)P * ne;                       // [P]: this member's source ranges
+    int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
@@ -689,6 +705,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
     for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
+    for (int k = threadIdx.x; k < P; k += blockDim.x) srcsh[k] = A.src ? A.src[(size_t)k * Sact + cW] : ((Sact - 1) << 8);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool syncw = wv >= ne;                        // see k_xtan_back
     const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
@@ -731,16 +748,12 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
             polr = R.pol[(size_t)t * G + (size_t)e * na];
         }
     };
-    unsigned episode = 1;
-    xbar_arrive(!syncw);
+    xbar_arrive(!syncw);                                // the zeroed state has reached L2: episode 1
+    if (sync_duty) xpublish(A.sy, x, cW, 1u);
     prefetch(0);
-    xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
     int cur = 0;
     bool vnz = false;
-    const int son = (x == 0 && cW == 0) ? 0 : ((x == 0 && cW == Sact / 3) ? 1 : -1);
-    (void)son;
     for (int t = 0; t < P; t++) {
-        XSTAMP(1, son, t, 0);
         const size_t base = (size_t)t * G + (size_t)e * na;
         const size_t hb = (size_t)cur * hs;
         const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;
@@ -750,6 +763,8 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
         double acc[D];
 #pragma unroll
         for (int k = 0; k < D; k++) acc[k] = 0.0;
+        if (sync_duty) xpoll(A.sy, x, srcsh[t] & 255, srcsh[t] >> 8, (unsigned)(t + 1));   // this period's source members have published period t-1
+        xlds_barrier();
         if (!syncw) {
             clo = min(max(closh[t * ne + e], 0), na);
             double vT[D];
@@ -795,7 +810,6 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                     }
                 }
             }
-            XSTAMP(1, son, t, 1);
             {   // the mass point (see k_xprimal_fwd)
                 double cT[D];
 #pragma unroll
@@ -811,13 +825,10 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                     for (int k = 0; k < D; k++) acc[k] = cT[k];
                 }
             }
-            XSTAMP(1, son, t, 2);
             xtile_store_n<SL, D>(myt, acc);
         }
-        XSTAMPW(1, son, t, 6, ne - 1);
-        XSTAMPW(1, son, t, 7, ne / 2);
+        if (sync_duty) xpoll(A.sy, x, 0, Sact - 1, (unsigned)(t + 1));      // EVERY member is done reading the half about to be overwritten
         xlds_barrier();
-        XSTAMP(1, son, t, 3);
         vnz = vnz_next;
         const int nxt = cur ^ 1;
         if (!syncw) {
@@ -835,13 +846,58 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
             }
         }
         cur = nxt;
-        episode++;
-        XSTAMP(1, son, t, 4);
-        xbar_arrive(!syncw);
-        XSTAMP(1, son, t, 9);
+        xbar_arrive(!syncw);                            // this member's stores have reached L2: episode t+2
+        if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(t + 2));
         if (t + 1 < P) prefetch(t + 1);
-        xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
-        XSTAMP(1, son, t, 11);
+    }
+}
+
+// which members does member c gather from in period t? (lo | hi << 8), from the recorded primal; one block per (t, c)
+__global__ void k_xsrc_back(Consts c, Record R, int Sact, int *src) {
+    __shared__ int smin[256], smax[256];
+    const int t = blockIdx.x, m = blockIdx.y;
+    const int r0 = m * XRW, rows = min(XRW, c.n_a - r0);
+    int lo = 1 << 30, hi = -1;
+    for (int k = threadIdx.x; k < rows * c.n_e; k += blockDim.x) {
+        const int e = k / rows, a = r0 + (k - e * rows);
+        const size_t ro = (size_t)t * c.G + (size_t)e * c.n_a + a;
+        if (R.A[ro] != 0.0 || R.B[ro] != 0.0) { const int ib = R.ib[ro]; lo = min(lo, ib); hi = max(hi, ib + 1); }
+    }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)blockDim.x; k++) { lo = min(lo, smin[k]); hi = max(hi, smax[k]); }
+        int ml = m, mh = m;
+        if (hi >= 0) { ml = min(m, max(lo, 0) / XRW); mh = max(m, min(hi, c.n_a - 1) / XRW); }
+        src[(size_t)t * Sact + m] = ml | (mh << 8);
+    }
+}
+// the same for the forward sweep: the lottery segments of the member's target rows; when the virtual rows move through
+// source 0's lottery (some column was clamped last period, a column is not clamped now) their targets read EVERY member's slot
+__global__ void k_xsrc_fwd(Consts c, Record R, int Sact, int *src) {
+    __shared__ int smin[256], smax[256];
+    const int t = blockIdx.x, m = blockIdx.y;
+    const int r0 = m * XRW, rows = min(XRW, c.n_a - r0);
+    int lo = 1 << 30, hi = -1;
+    for (int k = threadIdx.x; k < rows * c.n_e; k += blockDim.x) {
+        const int e = k / rows, r = r0 + (k - e * rows);
+        const int4 sg = R.seg[(size_t)t * c.G + (size_t)e * c.n_a + r];
+        const int s0 = max(sg.x, 0), s2 = min(sg.z, c.n_a);
+        if (s2 > s0) { lo = min(lo, s0); hi = max(hi, s2 - 1); }
+    }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)blockDim.x; k++) { lo = min(lo, smin[k]); hi = max(hi, smax[k]); }
+        int ml = m, mh = m;
+        if (hi >= 0) { ml = min(m, lo / XRW); mh = max(m, hi / XRW); }
+        bool vnz = false, open = false;
+        for (int e = 0; e < c.n_e; e++) {
+            if (t > 0 && R.clo[(size_t)(t - 1) * c.n_e + e] > 0) vnz = true;
+            if (R.clo[(size_t)t * c.n_e + e] <= 0) open = true;
+        }
+        if (vnz && open) { ml = 0; mh = Sact - 1; }
+        src[(size_t)t * Sact + m] = ml | (mh << 8);
     }
 }
 

@@ -111,3 +111,32 @@ def test_forced_persistent_sweeps_error_surface(hank):
     hb.primal(x[2:4])
     assert hb.jvp(np.ones((2, 99, 2))).shape == (99, 2)
     hb.close()
+
+
+def test_persistent_sweeps_are_race_free_at_full_size(hank):
+    """2000x11, T=300 — every CU of every XCD busy, uneven work per member (the lottery segments near the borrowing
+    constraint are long): 25 repetitions of the tangent sweeps at one recorded primal, 32 directions and then a single one,
+    must reproduce the first result bit for bit (a lost hand-off between workgroups shows up as a difference), and two
+    columns agree with the oracle."""
+    m, ss, orc = ks_setup(2000, 11, 300)
+    P = 299
+    x, Z = ks_paths(m, ss, "x1", 0.01)
+    hb = forced_block(hank, m)
+    hb.set_boundary(ss.value, ss.D)
+    agg = hb.primal(x[2:4])
+    y = np.random.default_rng(21).standard_normal((2, P, 32))
+    first = hb.jvp(y)
+    one = hb.jvp(y[:, :, 7:8])
+    assert np.array_equal(one[:, 0], first[:, 7])          # a direction's result does not depend on its batch
+    for _ in range(25):
+        assert np.array_equal(hb.jvp(y), first)
+        assert np.array_equal(hb.jvp(y[:, :, 7:8]), one)
+    for _ in range(5):
+        assert np.array_equal(hb.primal(x[2:4]), agg)
+    xr = np.zeros((P, 3)); xw = np.zeros((P, 3))
+    xr[:, 0], xw[:, 0] = x[2], x[3]
+    xr[:, 1:], xw[:, 1:] = y[0][:, [3, 30]], y[1][:, [3, 30]]
+    st, oagg, _ = orc.household_block(xr, xw, ss.value, ss.D, 2)
+    assert st == 0
+    close(agg, oagg[:, 0]); close(first[:, [3, 30]], oagg[:, 1:])
+    hb.close()
