@@ -439,16 +439,17 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
     const double a_top = c.a[na - 1];
     if (own || virt) sP[slot] = own ? A.D0[pt] : 0.0;   // D_0 into state[0]
     // this lane's own-row record of the period about to be processed, fetched between the halves of the previous barrier
-    int4 sg = make_int4(0, 0, 0, 0);
+    int sg0 = 0, sg1 = 0, sg2 = 0;
     double polr = 0.0, lwr = 0.0, igr = 0.0;
-    auto prefetch = [&](int t) {
-        const size_t base = (size_t)t * G + (size_t)e * na;
-        if (own) { sg = R.seg[base + r]; polr = R.pol[base + r]; lwr = R.lw[base + r]; igr = R.ig[base + r]; }
-        else if (virt) polr = R.pol[base];              // a virtual row sits at the first grid point
-    };
+#define XPF_PREFETCH(T)                                                                                              \
+    do {                                                                                                             \
+        const size_t pb_ = (size_t)(T) * G + (size_t)e * na;                                                         \
+        if (own) { const int4 q_ = R.seg[pb_ + r]; sg0 = q_.x; sg1 = q_.y; sg2 = q_.z; polr = R.pol[pb_ + r]; lwr = R.lw[pb_ + r]; igr = R.ig[pb_ + r]; } \
+        else if (virt) polr = R.pol[pb_];              /* a virtual row sits at the first grid point */             \
+    } while (0)
     unsigned episode = 1;
     xbar_arrive(!syncw);
-    prefetch(0);
+    XPF_PREFETCH(0);
     xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
     int cur = 0;
     bool vnz = false;                                   // the virtual rows may hold mass: some column was clamped last period
@@ -474,7 +475,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
                 double Dfull = xld(Dp + r);
                 if (r == 0 && clo == 0) Dfull += vD;
                 R.lwg[base + r] = make_double2(lwr, igr * Dfull);
-                const int s0 = max(sg.x, 0), s2 = min(sg.z, na);      // (a record that is not a lottery must not turn into a long loop)
+                const int s0 = max(sg0, 0), s2 = min(sg2, na);        // (a record that is not a lottery must not turn into a long loop)
                 // sources two at a time: both sources' loads are in flight before either is used
                 for (int j0 = s0; j0 < s2; j0 += 2) {
                     double pj[2], Dj[2];
@@ -490,7 +491,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
                     for (int u = 0; u < 2; u++) {
                         const int j = j0 + u;
                         if (!on[u]) continue;
-                        const bool first = j < sg.y;                      // source's upper target is this row
+                        const bool first = j < sg1;                       // source's upper target is this row
                         if (j == 0) Dj[u] += vD;     // (then clo == 0) row 0's virtual rows follow row 0's interior lottery
                         // Young lottery of source j (ForwardIteration.jl:59-73; same expressions as k_lottery)
                         const double al = first ? a_m : a_0, gap = first ? a_0 - a_m : a_p - a_0;
@@ -532,9 +533,10 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
         cur = nxt;
         episode++;
         xbar_arrive(!syncw);
-        if (t + 1 < P) prefetch(t + 1);
+        if (t + 1 < P) XPF_PREFETCH(t + 1);
         xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
     }
+#undef XPF_PREFETCH
 }
 
 // ================================ tangent-only sweeps at a recorded primal ===================================
