@@ -564,8 +564,8 @@ static int x_run_primal(hank_ctx *ctx) {
     ab.err = ctx->d_err; ab.R = ctx->R;
     XFwdArgs af{};
     af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.sy = X.sync + 1; af.st_D = X.st_D; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart;
-    const size_t ldsb = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * P) + 64;
-    const size_t ldsf = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * P * c.n_e + 64;
+    const size_t ldsb = sizeof(double) * ((size_t)c.n_e * 64 + c.n_a + 4 * P) + 64;
+    const size_t ldsf = sizeof(double) * ((size_t)c.n_e * 64) + sizeof(int) * P * c.n_e + 64;
     HIPC(ctx, hipEventRecord(ctx->ev[0], s));
     if (X.maxt == 768) x_launch_primal<768>(true, grd, blk, ldsb, s, ab, af);
     else x_launch_primal<1024>(true, grd, blk, ldsb, s, ab, af);
@@ -627,7 +627,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
         const XPass &ps = w->passes[p];
         ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
         const int SLt = ps.D == 4 ? 6 : ps.D;      // XTileT<D>::SL
-        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + P + 3 * P * ps.D) + sizeof(int) * P + 64;
+        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + P + 1 + 3 * P * ps.D) + sizeof(int) * P + 64;
         if (X.maxt == 768) x_launch_tan<768>(ps.D, true, grd, blk, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, true, grd, blk, lds, s, ab, af);
     }
@@ -638,7 +638,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
         const XPass &ps = w->passes[p];
         af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.N = ps.N; af.dpol = w->dpol + ps.dpol_off;
         const int SLt = ps.D == 4 ? 6 : ps.D;
-        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * (P * c.n_e + P) + 64;
+        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64) + sizeof(int) * (P * c.n_e + P) + 64;
         if (X.maxt == 768) x_launch_tan<768>(ps.D, false, grd, blkF, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, false, grd, blkF, lds, s, ab, af);
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));

@@ -300,6 +300,26 @@ __device__ __forceinline__ void xtile_mix(const double *tl, const double *P, int
     }
 }
 
+// the same with the column of Pi held in registers (16 unrolled steps, the ones beyond n_e predicated off): no LDS read for
+// the coefficient, and every tile read of the pass can be in flight at once
+template <int SL, int NS>
+__device__ __forceinline__ void xtile_mix_reg(const double *tl, const double (&pr)[16], int ne, double *out) {
+    const int ks = 64 * SL;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < ne) {
+            double v[SL];
+            if (SL == 1) v[0] = tl[(size_t)k * ks];
+            else {
+#pragma unroll
+                for (int q = 0; q < (NS + 1) / 2; q++) { const double2 d = reinterpret_cast<const double2 *>(tl + (size_t)k * ks)[q]; v[2 * q] = d.x; v[2 * q + 1] = d.y; }
+            }
+#pragma unroll
+            for (int q = 0; q < NS; q++) out[q] = k == 0 ? pr[k] * v[q] : out[q] + pr[k] * v[q];
+        }
+    }
+}
+
 // ================================ the Float64 sweeps ==========================================
 // One group (the XCD with id 0) runs them; the workgroups that landed elsewhere leave at once. They write the policy
 // sequence, the distribution path and the linearisation record the tangent sweeps — of either implementation — read.
@@ -320,8 +340,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
     const Consts &c = A.c;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     double *Vsh = xl;                                   // [ne][64]
-    double *Pish = Vsh + (size_t)ne * 64;               // [ne*ne]
-    double *ash = Pish + ne * ne;                       // [na]: the wealth grid (the bracket's grid values are a dependent load)
+    double *ash = Vsh + (size_t)ne * 64;                      // [na]: the wealth grid (the bracket's grid values are a dependent load)
     double *xsh = ash + na;                             // [P][4]: r_t, w_t, tr_t, rho_t — a cold uniform load per period otherwise
     int *ctl = reinterpret_cast<int *>(xsh + 4 * (size_t)P);
     const XGroup g = xgroup_join(A.sy, ctl);
@@ -338,7 +357,9 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
     const int a = cW * XRW + lane;
     const bool own = !syncw && lane < XRW && a < na;
     const size_t pt = (size_t)e * na + (own ? a : 0);
-    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    double pr[16];                                      // Pi[e, k]: this wave's coefficients of the expectation
+#pragma unroll
+    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[e + ne * k] : 0.0;
     for (int k = threadIdx.x; k < na; k += blockDim.x) ash[k] = c.a[k];
     for (int k = threadIdx.x; k < P; k += blockDim.x) {
         xsh[4 * k] = A.xhh[c.n_hh * k]; xsh[4 * k + 1] = A.xhh[c.n_hh * k + 1]; xsh[4 * k + 2] = hh_tr(c, A.xhh, k); xsh[4 * k + 3] = A.rho[k];
@@ -375,7 +396,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
             const int tx = P - 1 - i;
             if (own) {
                 double E;
-                xtile_mix<1, 1>(Vsh + lane, Pish + e, ne, ne, &E);
+                xtile_mix_reg<1, 1>(Vsh + lane, pr, ne, &E);
                 const double bE = E * c.beta;
                 const double ex = -1.0 / c.gamma;
                 if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);
@@ -411,8 +432,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     const int GV = G + 64 * ne;
     double *tile = xl;                                  // [ne][64]
-    double *Pish = tile + (size_t)ne * 64;
-    int *closh = reinterpret_cast<int *>(Pish + ne * ne);      // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
+    int *closh = reinterpret_cast<int *>(tile + (size_t)ne * 64);     // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
     int *ctl = closh + (size_t)P * ne;
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
@@ -431,7 +451,9 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
     const bool virt = !syncw && lane == 63;             // this wave's virtual row: slot cW of column e
     const size_t pt = (size_t)e * na + (own ? r : 0);
     const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;      // where this lane's state lives (virtual lanes: the tail)
-    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    double pr[16];                                      // Pi[k, e] as this wave's mixing uses it
+#pragma unroll
+    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[ne * e + k] : 0.0;
     const size_t hs = (size_t)XG * GV;                  // the other half of the ping-pong state
     double *const sP = A.st_D;
     // lottery geometry of this lane's row as a TARGET: sources of its first segment have bracket r-1, of its second r
@@ -519,7 +541,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
         if (!syncw) {
             // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99)
             double Dn;
-            xtile_mix<1, 1>(tile + lane, Pish + ne * e, 1, ne, &Dn);
+            xtile_mix_reg<1, 1>(tile + lane, pr, ne, &Dn);
             if (own || virt) {
                 sP[(size_t)nxt * hs + slot] = Dn;
                 if (own) R.Dseq[(size_t)(t + 1) * G + pt] = Dn;
@@ -570,9 +592,8 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     const Record &R = A.R;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     double *tile = xl;                                  // [ne][64][SL]
-    double *Pish = tile + (size_t)SL * ne * 64;
-    double *rhosh = Pish + ne * ne;                     // [P]
-    double *dxsh = rhosh + P;                           // [P][3][D]: this group's dr, dw, dtr (a cold uniform load per period otherwise)
+    double *rhosh = tile + (size_t)SL * ne * 64;                    // [P]
+    double *dxsh = rhosh + ((P + 1) & ~1);                       // [P][3][D]: this group's dr, dw, dtr (a cold uniform load per period otherwise)
     int *srcsh = reinterpret_cast<int *>(dxsh + (size_t)P * 3 * D);      // [P]: this member's source ranges
     int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
@@ -599,7 +620,6 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     const int r0 = cW * XRW, a = r0 + lane;
     const bool own = !syncw && lane < XRW && a < na;
     const size_t pt = (size_t)e * na + (own ? a : 0);
-    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     const double ze = c.z[e], xa = c.a[own ? a : 0];
     const size_t hs = (size_t)XG * G;
     double *const sD = A.st_ds + (size_t)x * G * D;
@@ -613,6 +633,9 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
         if (!syncw) xtile_store_n<SL, D>(myt, z);       // dV_T = 0 (BackwardIteration.jl:85)
     }
     __syncthreads();
+    double pr[16];                                      // Pi[e, k]: this wave's coefficients of the mixing
+#pragma unroll
+    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[e + ne * k] : 0.0;
     // the record of the period each half is about to use, fetched one trip ahead: the loads are issued between the two
     // halves of the group barrier and land while the group meets
     int ibY = 0;
@@ -655,7 +678,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
             if (own) {
                 const double rho = rhosh[tx];
                 double mx[D], ds[D];
-                xtile_mix<SL, D>(tile + (size_t)lane * SL, Pish + e, ne, ne, mx);
+                xtile_mix_reg<SL, D>(tile + (size_t)lane * SL, pr, ne, mx);
 #pragma unroll
                 for (int k = 0; k < D; k++) {
                     const double dr1 = dxsh[(tx * 3 + 0) * D + k], dw1 = dxsh[(tx * 3 + 1) * D + k], dt1 = dxsh[(tx * 3 + 2) * D + k];
@@ -695,8 +718,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     const int GV = G + 64 * ne;
     double *tile = xl;
-    double *Pish = tile + (size_t)SL * ne * 64;
-    int *closh = reinterpret_cast<int *>(Pish + ne * ne);      // [P][ne]
+    int *closh = reinterpret_cast<int *>(tile + (size_t)SL * ne * 64);     // [P][ne]
     int *srcsh = closh + (size_t)P * ne;                       // [P]: this member's source ranges
     int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
@@ -717,7 +739,9 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     const bool virt = !syncw && lane == 63;
     const size_t pt = (size_t)e * na + (own ? r : 0);
     const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;
-    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    double pr[16];                                      // Pi[k, e] as this wave's mixing uses it
+#pragma unroll
+    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[ne * e + k] : 0.0;
     const size_t hs = (size_t)XG * GV;
     double *const sT = A.st_dD + (size_t)x * GV * D;
     XRows<D> rows;
@@ -835,7 +859,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
         const int nxt = cur ^ 1;
         if (!syncw) {
             double mx[D];
-            xtile_mix<SL, D>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
+            xtile_mix_reg<SL, D>(tile + (size_t)lane * SL, pr, ne, mx);
             if (own || virt) xstore_row<D>(sT + ((size_t)nxt * hs + slot) * D, mx);
             // aggregate partials: pol_t dD_t + dpol_t D_t on real rows; a virtual row carries row 0's policy, its share of
             // D_t[0] is already in the recorded D_t[0]
