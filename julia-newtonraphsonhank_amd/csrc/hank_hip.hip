@@ -564,7 +564,7 @@ static int x_run_primal(hank_ctx *ctx) {
     ab.err = ctx->d_err; ab.R = ctx->R;
     XFwdArgs af{};
     af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.sy = X.sync + 1; af.st_D = X.st_D; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart;
-    const size_t ldsb = sizeof(double) * ((size_t)c.n_e * 64 + c.n_a + 4 * P) + 64;
+    const size_t ldsb = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * P) + 64;
     const size_t ldsf = sizeof(double) * ((size_t)c.n_e * 64) + sizeof(int) * P * c.n_e + 64;
     HIPC(ctx, hipEventRecord(ctx->ev[0], s));
     if (X.maxt == 768) x_launch_primal<768>(true, grd, blk, ldsb, s, ab, af);

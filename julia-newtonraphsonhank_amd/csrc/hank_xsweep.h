@@ -340,7 +340,8 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
     const Consts &c = A.c;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     double *Vsh = xl;                                   // [ne][64]
-    double *ash = Vsh + (size_t)ne * 64;                      // [na]: the wealth grid (the bracket's grid values are a dependent load)
+    double *Pish = Vsh + (size_t)ne * 64;               // [ne*ne] (registers for it would spill the 1024-thread variant)
+    double *ash = Pish + ne * ne;                      // [na]: the wealth grid (the bracket's grid values are a dependent load)
     double *xsh = ash + na;                             // [P][4]: r_t, w_t, tr_t, rho_t — a cold uniform load per period otherwise
     int *ctl = reinterpret_cast<int *>(xsh + 4 * (size_t)P);
     const XGroup g = xgroup_join(A.sy, ctl);
@@ -357,9 +358,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
     const int a = cW * XRW + lane;
     const bool own = !syncw && lane < XRW && a < na;
     const size_t pt = (size_t)e * na + (own ? a : 0);
-    double pr[16];                                      // Pi[e, k]: this wave's coefficients of the expectation
-#pragma unroll
-    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[e + ne * k] : 0.0;
+    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     for (int k = threadIdx.x; k < na; k += blockDim.x) ash[k] = c.a[k];
     for (int k = threadIdx.x; k < P; k += blockDim.x) {
         xsh[4 * k] = A.xhh[c.n_hh * k]; xsh[4 * k + 1] = A.xhh[c.n_hh * k + 1]; xsh[4 * k + 2] = hh_tr(c, A.xhh, k); xsh[4 * k + 3] = A.rho[k];
@@ -396,7 +395,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
             const int tx = P - 1 - i;
             if (own) {
                 double E;
-                xtile_mix_reg<1, 1>(Vsh + lane, pr, ne, &E);
+                xtile_mix<1, 1>(Vsh + lane, Pish + e, ne, ne, &E);
                 const double bE = E * c.beta;
                 const double ex = -1.0 / c.gamma;
                 if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);
@@ -642,12 +641,16 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     double cA = 0.0, cB = 0.0, cu = 0.0, cv = 0.0, ck = 0.0, cs = 0.0;
     if (own) { ck = R.kc[(size_t)(P - 1) * G + pt]; cs = R.s[(size_t)(P - 1) * G + pt]; }
     // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0); member c publishes episode i+1 when the stores of trip i have drained
+    const int son = x == 0 ? (cW == 0 ? 0 : (cW == Sact / 3 ? 1 : -1)) : -1;     // dev stamps (make stamp)
+    (void)son;
     for (int i = 0; i <= P; i++) {
+        XSTAMP(0, son, i, 0);
         if (i > 0) {
             // ---- Y-tangent of period t: dg = A ds[ib] + B ds[ib+1]; dV = u dr + v ((a dr + z dw + dtr) - dg)
             const int t = P - i, cur = (i - 1) & 1;
             if (sync_duty) xpoll(A.sy, x, srcsh[t] & 255, srcsh[t] >> 8, (unsigned)i);    // the members this period gathers from have published trip i-1
             xlds_barrier();
+            XSTAMP(0, son, i, 1);
             double dV[D];
 #pragma unroll
             for (int k = 0; k < D; k++) dV[k] = 0.0;
@@ -669,8 +672,10 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                 xstore_row<D>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * D, dg);
             }
             if (!syncw) xtile_store_n<SL, D>(myt, dV);
+            XSTAMP(0, son, i, 2);
             if (sync_duty) xpoll(A.sy, x, 0, Sact - 1, (unsigned)i);      // EVERY member is done reading the half the X half overwrites
             xlds_barrier();
+            XSTAMP(0, son, i, 3);
         }
         if (i < P) {
             // ---- X-tangent of period tx: ds = kc dE - rho ((z dw + dtr) + s dr)
@@ -686,7 +691,9 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                 }
                 xstore_row<D>(sD + ((size_t)(i & 1) * hs + pt) * D, ds);
             }
+            XSTAMP(0, son, i, 4);
             xbar_arrive(!syncw);                                         // this member's stores have reached L2
+            XSTAMP(0, son, i, 5);
             if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(i + 1));
             if (own) {      // the record the next trip needs (Y of period tx, X of period tx - 1): in flight while the others arrive
                 const size_t ro = (size_t)tx * G + pt;
@@ -779,7 +786,10 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     prefetch(0);
     int cur = 0;
     bool vnz = false;
+    const int son = x == 0 ? (cW == 0 ? 0 : (cW == Sact / 3 ? 1 : -1)) : -1;     // dev stamps (make stamp)
+    (void)son;
     for (int t = 0; t < P; t++) {
+        XSTAMP(1, son, t, 0);
         const size_t base = (size_t)t * G + (size_t)e * na;
         const size_t hb = (size_t)cur * hs;
         const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;
@@ -791,6 +801,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
         for (int k = 0; k < D; k++) acc[k] = 0.0;
         if (sync_duty) xpoll(A.sy, x, srcsh[t] & 255, srcsh[t] >> 8, (unsigned)(t + 1));   // this period's source members have published period t-1
         xlds_barrier();
+        XSTAMP(1, son, t, 1);
         if (!syncw) {
             clo = min(max(closh[t * ne + e], 0), na);
             double vT[D];
@@ -836,6 +847,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                     }
                 }
             }
+            XSTAMP(1, son, t, 2);
             {   // the mass point (see k_xprimal_fwd)
                 double cT[D];
 #pragma unroll
@@ -853,8 +865,10 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
             }
             xtile_store_n<SL, D>(myt, acc);
         }
+        XSTAMP(1, son, t, 3);
         if (sync_duty) xpoll(A.sy, x, 0, Sact - 1, (unsigned)(t + 1));      // EVERY member is done reading the half about to be overwritten
         xlds_barrier();
+        XSTAMP(1, son, t, 4);
         vnz = vnz_next;
         const int nxt = cur ^ 1;
         if (!syncw) {
@@ -872,8 +886,10 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
             }
         }
         cur = nxt;
+        XSTAMP(1, son, t, 5);
         xbar_arrive(!syncw);                            // this member's stores have reached L2: episode t+2
         if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(t + 2));
+        XSTAMP(1, son, t, 6);
         if (t + 1 < P) prefetch(t + 1);
     }
 }

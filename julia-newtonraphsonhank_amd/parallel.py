@@ -48,24 +48,32 @@ def sharded_jvp(jvp_fn: Callable[[torch.Tensor], torch.Tensor], tangents: torch.
 
 
 def assemble_columns(jvp_block: Callable, n: int, chunk: int = 512, group=None, device=None):
-    """J = [J·e_1 ... J·e_n] from unit tangents, `chunk` columns per rank and call; with W ranks every pass covers
-    W·chunk columns, each rank pushes its own slice through `jvp_block` ((n, k) numpy -> (m, k) numpy) and one
-    all-gather per pass puts the finished columns on every rank (the Jacobian assembly of SURVEY.md §8e).
+    """J = [J·e_1 ... J·e_n] from unit tangents (the Jacobian assembly of SURVEY.md §8e): rank g owns the contiguous
+    column range `shard_bounds(n, W, g)`, pushes it through `jvp_block` ((n, k) numpy -> (m, k) numpy: household block on
+    the GPU, residual layer on the host) `chunk` columns per call, and ONE all-gather at the end puts the finished
+    matrix on every rank — no collective per pass, nothing but the finished block crosses to the device for it.
     `device`: where the gathered blocks live ("cuda" for the nccl backend, CPU for gloo)."""
     import numpy as np
     W = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if W > 1 else 0
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if (W > 1 and dist.get_backend(group) == "nccl") else torch.device("cpu")
-
-    def fn(block: torch.Tensor) -> torch.Tensor:
-        if block.shape[1] == 0:        # a rank with nothing to do in the last pass (the system is square: m = n rows)
-            return torch.empty((n, 0), dtype=torch.float64, device=device)
-        return torch.from_numpy(np.ascontiguousarray(jvp_block(block.cpu().numpy()))).to(device)
-
-    cols = []
-    for c0 in range(0, n, chunk * W):
-        c1 = min(n, c0 + chunk * W)
-        E = torch.zeros((n, c1 - c0), dtype=torch.float64)
-        E[torch.arange(c0, c1), torch.arange(c1 - c0)] = 1.0
-        cols.append(sharded_jvp(fn, E.to(device), group).cpu())
-    return torch.cat(cols, dim=1).numpy()
+    lo, hi = shard_bounds(n, W, rank)
+    blocks = []
+    for c0 in range(lo, hi, chunk):
+        c1 = min(hi, c0 + chunk)
+        E = np.zeros((n, c1 - c0))
+        E[np.arange(c0, c1), np.arange(c1 - c0)] = 1.0
+        blocks.append(np.ascontiguousarray(jvp_block(E)))
+    local = np.concatenate(blocks, axis=1) if blocks else np.empty((n, 0))      # (the system is square: m = n rows)
+    if W == 1:
+        return local
+    kmax = -(-n // W)
+    padded = torch.zeros((kmax, local.shape[0]), dtype=torch.float64)
+    padded[: hi - lo] = torch.from_numpy(local.T.copy())
+    padded = padded.to(device)
+    out = torch.empty((W * kmax, local.shape[0]), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    out = out.cpu()
+    rows = [out[r * kmax: r * kmax + (shard_bounds(n, W, r)[1] - shard_bounds(n, W, r)[0])] for r in range(W)]
+    return torch.cat(rows, dim=0).t().contiguous().numpy()
