@@ -113,7 +113,7 @@ if __name__ == "__main__":
             print("HANK_XRUNAHEAD =", mask, flush=True)
             timing(2000, 11, 300, [1, 32], scheds=("xcd",))
     if what == "tx":      # the persistent sweeps alone, the widths that matter
-        timing(2000, 11, 300, [1, 16, 32], scheds=("xcd",))
+        timing(2000, 11, 300, [1, 16, 32, 64], scheds=("xcd",))
     if what in ("all", "time"):
         timing(2000, 11, 300, [1, 8, 16, 32, 64, 128, 256])
         timing(500, 4, 300, [1, 32])
