@@ -457,7 +457,8 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.st_s, 2 * XG * G));
     HIPC(ctx, dmalloc(&X.st_ds, 2 * XG * G * X.dmax));
     HIPC(ctx, dmalloc(&X.st_D, 2 * XG * GV));
-    HIPC(ctx, dmalloc(&X.st_dD, 2 * XG * GV * X.dmax));
+    const size_t GM = (size_t)c.n_e * X.Sact * 64;       // member-major state of the tangent forward sweep: [n_e][members][64]
+    HIPC(ctx, dmalloc(&X.st_dD, 2 * XG * GM * X.dmax));
     HIPC(ctx, dmalloc(&X.Dvirt, P * c.n_e * 64));
     HIPC(ctx, dmalloc(&X.aggpart, P * (size_t)X.Sact * c.n_e));
     HIPC(ctx, dmalloc(&X.rho, P));
@@ -638,7 +639,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
         const XPass &ps = w->passes[p];
         af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.N = ps.N; af.dpol = w->dpol + ps.dpol_off;
         const int SLt = ps.D == 4 ? 6 : ps.D;
-        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64) + sizeof(int) * (P * c.n_e + P) + 64;
+        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * (P * c.n_e + P) + 64;
         if (X.maxt == 768) x_launch_tan<768>(ps.D, false, grd, blkF, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, false, grd, blkF, lds, s, ab, af);
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
@@ -1109,6 +1110,7 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
 int hank_debug_stamps(hank_ctx *ctx, unsigned long long *out) {
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     HIPC(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(hank::g_xstamps), sizeof(unsigned long long) * 2 * 2 * XSTAMP_NP * XSTAMP_NS));
+    HIPC(ctx, hipMemcpyFromSymbol(out + 2 * 2 * XSTAMP_NP * XSTAMP_NS, HIP_SYMBOL(hank::g_xwaves), sizeof(unsigned long long) * 2 * 2 * XSTAMP_NP * 16));
     return HANK_OK;
 }
 #endif

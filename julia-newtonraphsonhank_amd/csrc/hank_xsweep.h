@@ -35,6 +35,9 @@
 
 namespace hank {
 
+#ifndef HANK_XFWD_NS4
+#define HANK_XFWD_NS4 3
+#endif
 constexpr int XG = 8;             // groups = XCDs
 constexpr int XRW = 63;           // wealth rows per workgroup; lane 63 of every wave is the forward sweep's virtual row
 constexpr unsigned XSPIN_LIMIT = 1u << 21;
@@ -58,25 +61,37 @@ __device__ __forceinline__ double xld(const double *p) {      // 8-byte sc1 load
 __device__ __forceinline__ unsigned xldu(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // one row of D partials (8*D bytes, 8*D-aligned) with sc1 loads: 16-byte buffer loads where the row allows
+// The state of D partials per row is kept as D/2 PLANES of 16-byte pairs ([plane][row][2]; D = 1: [row]): one store
+// instruction then writes 16 contiguous bytes per lane, whole lines per wave. With [row][D] a D = 4 row took two store
+// instructions that each wrote half of every 32-byte sector.
 template <int D>
 struct XRows {
     __amdgpu_buffer_rsrc_t rs;
-    const double *base;
-    __device__ __forceinline__ void init(const double *p, size_t bytes) {
-        base = p;
-        if (D >= 2) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, (int)bytes, 0x00020000);
+    double *base;
+    size_t plane;               // rows per plane = rows of the whole buffer
+    __device__ __forceinline__ void init(double *p, size_t rows_total) {
+        base = p; plane = rows_total;
+        if (D >= 2) rs = __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(rows_total * 8 * D), 0x00020000);
     }
-    // row index counts rows of D doubles from `base` (the ping-pong half is part of the row index)
+    // row index counts rows from `base` (ping-pong half and group are part of the row index)
     __device__ __forceinline__ void load(size_t row, double *v) const {
         if (D == 1) {
             v[0] = xld(base + row);
         } else {
 #pragma unroll
             for (int k = 0; k < D / 2; k++) {
-                const xv4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(row * (size_t)(8 * D)) + 16 * k, 0, 16);   // aux 16 = sc1
+                const xv4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((k * plane + row) * 16), 0, 16);   // aux 16 = sc1
                 v[2 * k] = __hiloint2double((int)q.y, (int)q.x);
                 v[2 * k + 1] = __hiloint2double((int)q.w, (int)q.z);
             }
+        }
+    }
+    __device__ __forceinline__ void store(size_t row, const double *v) const {      // plain stores: the line stays in the XCD's L2
+        if (D == 1) {
+            base[row] = v[0];
+        } else {
+#pragma unroll
+            for (int k = 0; k < D / 2; k++) reinterpret_cast<double2 *>(base)[k * plane + row] = make_double2(v[2 * k], v[2 * k + 1]);
         }
     }
 };
@@ -109,15 +124,30 @@ __device__ unsigned long long g_xstamps[2][2][XSTAMP_NP][XSTAMP_NS];      // [sw
 #define XSTAMP(sw, on, per, i)                                                                                   \
     do {                                                                                                         \
         if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && threadIdx.x == 0)                 \
-            g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memtime();                              \
+            g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memrealtime();                              \
     } while (0)
 // stamp taken by lane 0 of wave `wave` (arrival of the other waves at a workgroup barrier)
 #define XSTAMPW(sw, on, per, i, wave)                                                                            \
     do {                                                                                                         \
         if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (int)threadIdx.x == 64 * (wave))  \
-            g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memtime();                              \
+            g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memrealtime();                              \
+    } while (0)
+// every wave's arrival at one chosen point of the period (lane 0 of each wave)
+__device__ unsigned long long g_xwaves[2][2][XSTAMP_NP][16];
+#define XSTAMPV(sw, on, per)                                                                                     \
+    do {                                                                                                         \
+        if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (threadIdx.x & 63) == 0)          \
+            g_xwaves[sw][on][(per) - XSTAMP_T0][threadIdx.x >> 6] = __builtin_amdgcn_s_memrealtime();             \
+    } while (0)
+// wave `wave`'s lane 0 stamps slot `slot` (11..15: free columns of g_xwaves)
+#define XSTAMPS(sw, on, per, wave, slot)                                                                         \
+    do {                                                                                                         \
+        if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (int)threadIdx.x == 64 * (wave))  \
+            g_xwaves[sw][on][(per) - XSTAMP_T0][slot] = __builtin_amdgcn_s_memrealtime();                         \
     } while (0)
 #else
+#define XSTAMPS(sw, on, per, wave, slot) do {} while (0)
+#define XSTAMPV(sw, on, per) do {} while (0)
 #define XSTAMP(sw, on, per, i) do {} while (0)
 #define XSTAMPW(sw, on, per, i, wave) do {} while (0)
 #endif
@@ -621,9 +651,9 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     const size_t pt = (size_t)e * na + (own ? a : 0);
     const double ze = c.z[e], xa = c.a[own ? a : 0];
     const size_t hs = (size_t)XG * G;
-    double *const sD = A.st_ds + (size_t)x * G * D;
     XRows<D> rows;
-    rows.init(sD, (hs + G) * D * 8);
+    rows.init(A.st_ds, 2 * hs);
+    const size_t gx = (size_t)x * G;                    // this group's rows within a half
     double *const myt = tile + ((size_t)e * 64 + lane) * SL;
     {
         double z[D];
@@ -659,7 +689,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
 #pragma unroll
                 for (int k = 0; k < D; k++) d0[k] = d1[k] = 0.0;
                 if (cA != 0.0 || cB != 0.0) {
-                    const size_t rb = (size_t)cur * hs + (size_t)e * na;
+                    const size_t rb = (size_t)cur * hs + gx + (size_t)e * na;
                     rows.load(rb + ibY, d0);
                     rows.load(rb + ibY + 1, d1);
                 }
@@ -673,6 +703,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
             }
             if (!syncw) xtile_store_n<SL, D>(myt, dV);
             XSTAMP(0, son, i, 2);
+            XSTAMPV(0, son, i);
             if (sync_duty) xpoll(A.sy, x, 0, Sact - 1, (unsigned)i);      // EVERY member is done reading the half the X half overwrites
             xlds_barrier();
             XSTAMP(0, son, i, 3);
@@ -689,7 +720,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                     const double dr1 = dxsh[(tx * 3 + 0) * D + k], dw1 = dxsh[(tx * 3 + 1) * D + k], dt1 = dxsh[(tx * 3 + 2) * D + k];
                     ds[k] = ck * mx[k] - rho * ((ze * dw1 + dt1) + cs * dr1);
                 }
-                xstore_row<D>(sD + ((size_t)(i & 1) * hs + pt) * D, ds);
+                rows.store((size_t)(i & 1) * hs + gx + pt, ds);
             }
             XSTAMP(0, son, i, 4);
             xbar_arrive(!syncw);                                         // this member's stores have reached L2
@@ -719,13 +750,15 @@ struct XTanFwdArgs {
 template <int D, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     constexpr int SL = XTileT<D>::SL;
+    constexpr int NS = MAXT > 768 ? 2 : (D == 4 ? HANK_XFWD_NS4 : 4);      // sources per trip of the gather loop (registers)
+    constexpr bool PIREG = D < 4;                       // the mixing's coefficients in registers (D = 4 needs them for the gather)
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const Record &R = A.R;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
-    const int GV = G + 64 * ne;
     double *tile = xl;
-    int *closh = reinterpret_cast<int *>(tile + (size_t)SL * ne * 64);     // [P][ne]
+    double *Pish = tile + (size_t)SL * ne * 64;        // [ne*ne] (read when !PIREG)
+    int *closh = reinterpret_cast<int *>(Pish + ne * ne);     // [P][ne]
     int *srcsh = closh + (size_t)P * ne;                       // [P]: this member's source ranges
     int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
@@ -735,6 +768,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     const int Sact = (na + XRW - 1) / XRW;
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
+    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
     for (int k = threadIdx.x; k < P; k += blockDim.x) srcsh[k] = A.src ? A.src[(size_t)k * Sact + cW] : ((Sact - 1) << 8);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -744,21 +778,24 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     const int r0 = cW * XRW, r = r0 + lane;
     const bool own = !syncw && lane < XRW && r < na;
     const bool virt = !syncw && lane == 63;
-    const size_t pt = (size_t)e * na + (own ? r : 0);
-    const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;
+    // state layout [e][member][64][D]: a member's 63 rows and its virtual row (slot 63) are ONE line-aligned block of its
+    // column, written by one store instruction of one wave — no line is shared between two workgroups' partial writes
+    // (the reads of such lines took an HBM round trip: 1.8 us for the virtual rows of a column)
+    const size_t GV = (size_t)ne * Sact * 64;
+    const size_t gx = (size_t)x * GV;                   // this group's rows within a half of the ping-pong buffer
+    const size_t slot = gx + ((size_t)e * Sact + cW) * 64 + lane;
     double pr[16];                                      // Pi[k, e] as this wave's mixing uses it
 #pragma unroll
-    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[ne * e + k] : 0.0;
+    for (int k = 0; k < 16; k++) pr[k] = (PIREG && k < ne) ? c.Pi[ne * e + k] : 0.0;
     const size_t hs = (size_t)XG * GV;
-    double *const sT = A.st_dD + (size_t)x * GV * D;
     XRows<D> rows;
-    rows.init(sT, (hs + GV) * D * 8);
+    rows.init(A.st_dD, 2 * hs);
     double *const myt = tile + ((size_t)e * 64 + lane) * SL;
     {
         double z[D];
 #pragma unroll
         for (int k = 0; k < D; k++) z[k] = 0.0;
-        if (own || virt) xstore_row<D>(sT + slot * D, z);      // the initial distribution carries no partials
+        if (own || virt) rows.store(slot, z);           // the initial distribution carries no partials
     }
     // this lane's own-row record of the period about to be processed (segments, policy, D_t, policy partials): fetched
     // between the two halves of the previous group barrier
@@ -790,6 +827,8 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     (void)son;
     for (int t = 0; t < P; t++) {
         XSTAMP(1, son, t, 0);
+        XSTAMPW(1, son, t, 9, ne / 2);
+        XSTAMPW(1, son, t, 10, ne - 1);
         const size_t base = (size_t)t * G + (size_t)e * na;
         const size_t hb = (size_t)cur * hs;
         const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;
@@ -800,27 +839,39 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
 #pragma unroll
         for (int k = 0; k < D; k++) acc[k] = 0.0;
         if (sync_duty) xpoll(A.sy, x, srcsh[t] & 255, srcsh[t] >> 8, (unsigned)(t + 1));   // this period's source members have published period t-1
+        XSTAMPW(1, son, t, 7, ne);
         xlds_barrier();
         XSTAMP(1, son, t, 1);
         if (!syncw) {
             clo = min(max(closh[t * ne + e], 0), na);
-            double vT[D];
+            // the partials sitting on this column's virtual rows follow source row 0's lottery: only a wave with a target fed
+            // by row 0 needs their sum (one or two members per open column). Its loads fly during the gather, the sum (DPP,
+            // fixed order) enters with row 0's weight after it.
+            const bool need_vT = vnz && clo == 0 && __any(own && sg.x <= 0 && min(sg.z, na) > 0);
+            double vT[D], w0 = 0.0;
 #pragma unroll
             for (int k = 0; k < D; k++) vT[k] = 0.0;
-            if (vnz && clo == 0) {           // the partials sitting on this column's virtual rows follow source 0's lottery
-                if (lane < Sact) rows.load(hb + (size_t)G + (size_t)e * 64 + lane, vT);
+            if (need_vT && lane < Sact) rows.load(hb + gx + ((size_t)e * Sact + lane) * 64 + 63, vT);
+            // the mass point's inputs (this member's clamped rows, its own virtual row): in flight during the gather as well
+            double cT[D];
 #pragma unroll
-                for (int k = 0; k < D; k++) vT[k] = xwave_sum(vT[k]);
-            }
+            for (int k = 0; k < D; k++) cT[k] = 0.0;
+            if (own && r < clo) rows.load(hb + slot, cT);
+            if (virt && clo > 0 && vnz) rows.load(hb + slot, cT);
             if (own) {
                 const int s0 = max(sg.x, 0), s2 = min(sg.z, na);   // (a record that is not a lottery must not turn into a long loop)
-                // sources two at a time: both sources' loads are in flight before either is used
-                for (int j0 = s0; j0 < s2; j0 += 2) {
-                    double2 wg[2];
-                    double dDj[2][D], dpj[2][D];
-                    bool on[2];
+                // sources NS at a time: all their loads are in flight before the first is used (a wave's gather costs one
+                // L2 round trip per trip of this loop, and the workgroup waits for its slowest wave: 3 sources on some row of
+                // most columns, up to 8 where high-income households leave the bottom of the grid)
+                XSTAMPS(1, son, t, ne - 1, 11);
+                int trip_ = 0;
+                (void)trip_;
+                for (int j0 = s0; j0 < s2; j0 += NS) {
+                    double2 wg[NS];
+                    double dDj[NS][D], dpj[NS][D];
+                    bool on[NS];
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
+                    for (int u = 0; u < NS; u++) {
                         const int j = j0 + u;
                         on[u] = j < s2;
                         wg[u] = make_double2(0.0, 0.0);
@@ -828,32 +879,46 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                         for (int k = 0; k < D; k++) dDj[u][k] = dpj[u][k] = 0.0;
                         if (on[u]) {
                             wg[u] = R.lwg[base + j];
-                            rows.load(hb + (size_t)e * na + j, dDj[u]);
+                            rows.load(hb + gx + ((size_t)e * Sact + j / XRW) * 64 + j % XRW, dDj[u]);
                             xload_row_plain<D>(A.dpol + (dbase + j) * D, dpj[u]);
                         }
                     }
+#ifdef HANK_XSTAMP
+                    if (trip_ == 0) {       // which of the first trip's loads is the late one? (in-order return: each wait includes the earlier loads)
+                        asm volatile("" ::"v"(vT[0]), "v"(cT[0]));
+                        XSTAMPS(1, son, t, ne - 1, 12);
+                        asm volatile("" ::"v"(wg[0].x));
+                        XSTAMPS(1, son, t, ne - 1, 13);
+                        asm volatile("" ::"v"(dDj[0][0]));
+                        XSTAMPS(1, son, t, ne - 1, 14);
+                        asm volatile("" ::"v"(dpj[0][0]));
+                        XSTAMPS(1, son, t, ne - 1, 15);
+                    }
+#endif
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
+                    for (int u = 0; u < NS; u++) {
                         const int j = j0 + u;
                         if (!on[u]) continue;
                         const bool first = j < sg.y;
-                        if (j == 0) {
-#pragma unroll
-                            for (int k = 0; k < D; k++) dDj[u][k] += vT[k];
-                        }
                         const double wt = first ? wg[u].x : 1.0 - wg[u].x;
+                        if (j == 0) w0 = wt;
 #pragma unroll
                         for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[u][k] + wg[u].y * dpj[u][k]) : (wt * dDj[u][k] - wg[u].y * dpj[u][k]);
                     }
+                    asm volatile("" ::"v"(acc[0]));
+                    trip_++;
+                }
+            }
+            if (need_vT) {
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    const double sv = xwave_reduce63(vT[k]);        // valid in lane 63
+                    const double sb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sv), 63), __builtin_amdgcn_readlane(__double2loint(sv), 63));
+                    acc[k] += w0 * sb;
                 }
             }
             XSTAMP(1, son, t, 2);
             {   // the mass point (see k_xprimal_fwd)
-                double cT[D];
-#pragma unroll
-                for (int k = 0; k < D; k++) cT[k] = 0.0;
-                if (own && r < clo) rows.load(hb + (size_t)e * na + r, cT);
-                if (virt && clo > 0 && vnz) rows.load(hb + slot, cT);
                 if (clo > r0) {
 #pragma unroll
                     for (int k = 0; k < D; k++) cT[k] = xwave_reduce63(cT[k]);
@@ -866,15 +931,18 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
             xtile_store_n<SL, D>(myt, acc);
         }
         XSTAMP(1, son, t, 3);
+        XSTAMPV(1, son, t);
         if (sync_duty) xpoll(A.sy, x, 0, Sact - 1, (unsigned)(t + 1));      // EVERY member is done reading the half about to be overwritten
+        XSTAMPW(1, son, t, 8, ne);
         xlds_barrier();
         XSTAMP(1, son, t, 4);
         vnz = vnz_next;
         const int nxt = cur ^ 1;
         if (!syncw) {
             double mx[D];
-            xtile_mix_reg<SL, D>(tile + (size_t)lane * SL, pr, ne, mx);
-            if (own || virt) xstore_row<D>(sT + ((size_t)nxt * hs + slot) * D, mx);
+            if (PIREG) xtile_mix_reg<SL, D>(tile + (size_t)lane * SL, pr, ne, mx);
+            else xtile_mix<SL, D>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
+            if (own || virt) rows.store((size_t)nxt * hs + slot, mx);
             // aggregate partials: pol_t dD_t + dpol_t D_t on real rows; a virtual row carries row 0's policy, its share of
             // D_t[0] is already in the recorded D_t[0]
             const bool live = own || virt;
@@ -889,6 +957,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
         XSTAMP(1, son, t, 5);
         xbar_arrive(!syncw);                            // this member's stores have reached L2: episode t+2
         if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(t + 2));
+        XSTAMPW(1, son, t, 11, ne);
         XSTAMP(1, son, t, 6);
         if (t + 1 < P) prefetch(t + 1);
     }
@@ -917,28 +986,31 @@ __global__ void k_xsrc_back(Consts c, Record R, int Sact, int *src) {
 // the same for the forward sweep: the lottery segments of the member's target rows; when the virtual rows move through
 // source 0's lottery (some column was clamped last period, a column is not clamped now) their targets read EVERY member's slot
 __global__ void k_xsrc_fwd(Consts c, Record R, int Sact, int *src) {
-    __shared__ int smin[256], smax[256];
+    __shared__ int smin[256], smax[256], any0;
     const int t = blockIdx.x, m = blockIdx.y;
     const int r0 = m * XRW, rows = min(XRW, c.n_a - r0);
-    int lo = 1 << 30, hi = -1;
+    int lo = 1 << 30, hi = -1, fed0 = 0;
+    if (threadIdx.x == 0) any0 = 0;
+    __syncthreads();
     for (int k = threadIdx.x; k < rows * c.n_e; k += blockDim.x) {
         const int e = k / rows, r = r0 + (k - e * rows);
         const int4 sg = R.seg[(size_t)t * c.G + (size_t)e * c.n_a + r];
         const int s0 = max(sg.x, 0), s2 = min(sg.z, c.n_a);
         if (s2 > s0) { lo = min(lo, s0); hi = max(hi, s2 - 1); }
+        // a target fed by source row 0 of an open column also takes what sits on EVERY member's virtual rows of that column
+        if (s2 > s0 && s0 == 0 && R.clo[(size_t)t * c.n_e + e] <= 0) fed0 = 1;
     }
     smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+    if (fed0) atomicOr(&any0, 1);
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < (int)blockDim.x; k++) { lo = min(lo, smin[k]); hi = max(hi, smax[k]); }
         int ml = m, mh = m;
         if (hi >= 0) { ml = min(m, lo / XRW); mh = max(m, hi / XRW); }
-        bool vnz = false, open = false;
-        for (int e = 0; e < c.n_e; e++) {
+        bool vnz = false;
+        for (int e = 0; e < c.n_e; e++)
             if (t > 0 && R.clo[(size_t)(t - 1) * c.n_e + e] > 0) vnz = true;
-            if (R.clo[(size_t)t * c.n_e + e] <= 0) open = true;
-        }
-        if (vnz && open) { ml = 0; mh = Sact - 1; }
+        if (vnz && any0) { ml = 0; mh = Sact - 1; }
         src[(size_t)t * Sact + m] = ml | (mh << 8);
     }
 }

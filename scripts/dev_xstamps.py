@@ -25,12 +25,15 @@ hb.set_boundary(ss.value, ss.D)
 y = np.random.default_rng(0).standard_normal((2, P, N))
 for _ in range(3):
     hb.primal(x[2:4]); hb.jvp(y)
-buf = (C.c_ulonglong * (2 * 2 * 8 * 12))()
+buf = (C.c_ulonglong * (2 * 2 * 8 * 12 + 2 * 2 * 8 * 16))()
 hb._lib.hank_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert hb._lib.hank_debug_stamps(hb._ctx, buf) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(2, 2, 8, 12).astype(np.int64)
+raw = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+st = raw[:2 * 2 * 8 * 12].reshape(2, 2, 8, 12)
+wv = raw[2 * 2 * 8 * 12:].reshape(2, 2, 8, 16)
 names = {0: ["top", "source poll + LDS barrier", "Y half: gathers, dV, dpol + tile store issued", "all-member poll + LDS barrier", "X half: mix, ds, state store issued", "arrived (stores drained, WG barrier)"],
-         1: ["top", "source poll + LDS barrier", "sources gathered", "mass point + tile store issued", "all-member poll + LDS barrier", "mix, state store, aggregate issued", "arrived + published"]}
+         1: ["top", "source poll + LDS barrier", "sources gathered", "mass point + tile store issued", "all-member poll + LDS barrier", "mix, state store, aggregate issued", "arrived + published",
+             "  sync wave: source poll done", "  sync wave: all-member poll done", "  wave ne/2 at top (its prefetch landed)", "  wave ne-1 at top", "  sync wave: published"]}
 tm = hb.last_timings()
 sweep_ms = {0: tm["tangent_backward"]["ms"], 1: tm["tangent_forward"]["ms"]}
 for sw, sname in ((0, "backward"), (1, "forward")):
@@ -47,3 +50,19 @@ for sw, sname in ((0, "backward"), (1, "forward")):
             print(f"   {names[sw][o]:28s} {med[k]:9.0f} ns")
         per = np.abs(np.diff(tops)) * tick_ns
         print(f"   period length (top to top)   {np.median(per):9.0f} ns   (1 tick = {tick_ns:.3f} ns)")
+
+# the two stamped members on one clock (s_memrealtime: one 100 MHz counter for the chip): who is ahead?
+for sw, sname in ((0, "backward"), (1, "forward")):
+    d = (st[sw, 0, :, 0] - st[sw, 1, :, 0]).astype(float)
+    tick = 1e6 * sweep_ms[sw] / P / float(np.median(np.abs(np.diff(st[sw, 0, :, 0]))))
+    print(f"{sname}: first member's top minus the other's top, same period: median {np.median(d) * tick:.0f} ns (min {d.min() * tick:.0f}, max {d.max() * tick:.0f})")
+
+# every wave's arrival at the end of the first half (Y half / gather + mass point + tile store), relative to wave 0
+for sw, sname in ((0, "backward"), (1, "forward")):
+    for mem, mname in ((0, "first member"), (1, "member at a third of the grid")):
+        rel = (wv[sw, mem, :, :11] - wv[sw, mem, :, [0]].reshape(-1, 1)) * 10.0
+        print(f"{sname}, {mname}: waves 0..10 at the end of the first half, ns after wave 0 (median): " + " ".join(f"{v:.0f}" for v in np.median(rel, axis=0)))
+
+for mem, mname in ((0, "first member"), (1, "member at a third of the grid")):
+    rel = (wv[1, mem, :, 11:16] - wv[1, mem, :, [11]].reshape(-1, 1)) * 10.0
+    print(f"forward, {mname}, wave ne-1: first trip of the gather: start, virtual rows + mass point inputs landed, lottery record of source 1 landed, its state row, its policy partials (ns, median): " + " ".join(f"{v:.0f}" for v in np.median(rel, axis=0)))
