@@ -25,9 +25,11 @@
 //     lengths) is LDS-resident for the whole sweep: as a per-period global load each is a cold round trip on the
 //     critical path.
 //
-// Layouts:  state  st_s [2][XG][G], st_ds [2][XG][G][D]                       (backward)
-//                  st_D [2][XG][G+64*n_e], st_dD [2][XG][G+64*n_e][D]         (forward; the tail holds the virtual rows)
-//           dpol   [P][groups][n_e][n_a][D]   — a group's stream is contiguous: whole lines, one XCD each.
+// Layouts:  Float64 state   st_s [2][XG][G] (backward), st_D [2][XG][G + 64*n_e] (forward; the tail holds the virtual rows)
+//           tangent state   D/2 PLANES of 16-byte pairs, [plane][2][XG][rows][2] (D = 1: [2][XG][rows]): a store instruction
+//                           writes 16 contiguous bytes per lane, whole lines per wave (XRows). rows = G backward; forward
+//                           [n_e][members][64]: a member's 63 rows + its virtual row (slot 63) are one line-aligned block
+//           dpol            [P][groups][n_e][n_a][D] — a group's stream is contiguous: whole lines, one XCD each.
 // What was measured on the way (a dual kernel carrying value and partials together, a run-ahead wave, atomic-counter
 // barriers, ...) is in DESIGN.md section 4.
 #pragma once
@@ -139,14 +141,7 @@ __device__ unsigned long long g_xwaves[2][2][XSTAMP_NP][16];
         if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (threadIdx.x & 63) == 0)          \
             g_xwaves[sw][on][(per) - XSTAMP_T0][threadIdx.x >> 6] = __builtin_amdgcn_s_memrealtime();             \
     } while (0)
-// wave `wave`'s lane 0 stamps slot `slot` (11..15: free columns of g_xwaves)
-#define XSTAMPS(sw, on, per, wave, slot)                                                                         \
-    do {                                                                                                         \
-        if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (int)threadIdx.x == 64 * (wave))  \
-            g_xwaves[sw][on][(per) - XSTAMP_T0][slot] = __builtin_amdgcn_s_memrealtime();                         \
-    } while (0)
 #else
-#define XSTAMPS(sw, on, per, wave, slot) do {} while (0)
 #define XSTAMPV(sw, on, per) do {} while (0)
 #define XSTAMP(sw, on, per, i) do {} while (0)
 #define XSTAMPW(sw, on, per, i, wave) do {} while (0)
@@ -863,9 +858,6 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                 // sources NS at a time: all their loads are in flight before the first is used (a wave's gather costs one
                 // L2 round trip per trip of this loop, and the workgroup waits for its slowest wave: 3 sources on some row of
                 // most columns, up to 8 where high-income households leave the bottom of the grid)
-                XSTAMPS(1, son, t, ne - 1, 11);
-                int trip_ = 0;
-                (void)trip_;
                 for (int j0 = s0; j0 < s2; j0 += NS) {
                     double2 wg[NS];
                     double dDj[NS][D], dpj[NS][D];
@@ -883,18 +875,6 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
                             xload_row_plain<D>(A.dpol + (dbase + j) * D, dpj[u]);
                         }
                     }
-#ifdef HANK_XSTAMP
-                    if (trip_ == 0) {       // which of the first trip's loads is the late one? (in-order return: each wait includes the earlier loads)
-                        asm volatile("" ::"v"(vT[0]), "v"(cT[0]));
-                        XSTAMPS(1, son, t, ne - 1, 12);
-                        asm volatile("" ::"v"(wg[0].x));
-                        XSTAMPS(1, son, t, ne - 1, 13);
-                        asm volatile("" ::"v"(dDj[0][0]));
-                        XSTAMPS(1, son, t, ne - 1, 14);
-                        asm volatile("" ::"v"(dpj[0][0]));
-                        XSTAMPS(1, son, t, ne - 1, 15);
-                    }
-#endif
 #pragma unroll
                     for (int u = 0; u < NS; u++) {
                         const int j = j0 + u;
@@ -905,8 +885,6 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
 #pragma unroll
                         for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[u][k] + wg[u].y * dpj[u][k]) : (wt * dDj[u][k] - wg[u].y * dpj[u][k]);
                     }
-                    asm volatile("" ::"v"(acc[0]));
-                    trip_++;
                 }
             }
             if (need_vT) {

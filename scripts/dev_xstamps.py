@@ -63,6 +63,3 @@ for sw, sname in ((0, "backward"), (1, "forward")):
         rel = (wv[sw, mem, :, :11] - wv[sw, mem, :, [0]].reshape(-1, 1)) * 10.0
         print(f"{sname}, {mname}: waves 0..10 at the end of the first half, ns after wave 0 (median): " + " ".join(f"{v:.0f}" for v in np.median(rel, axis=0)))
 
-for mem, mname in ((0, "first member"), (1, "member at a third of the grid")):
-    rel = (wv[1, mem, :, 11:16] - wv[1, mem, :, [11]].reshape(-1, 1)) * 10.0
-    print(f"forward, {mname}, wave ne-1: first trip of the gather: start, virtual rows + mass point inputs landed, lottery record of source 1 landed, its state row, its policy partials (ns, median): " + " ".join(f"{v:.0f}" for v in np.median(rel, axis=0)))
