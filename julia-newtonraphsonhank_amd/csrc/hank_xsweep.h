@@ -512,8 +512,13 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
             const double *Dp = sP + hb + (size_t)e * na;
             // the mass that sits on the virtual rows of this column (needed by the targets of source 0 when row 0 is not
             // clamped, and folded into D_{t-1}[0] there): summed by the wave, member order fixed
+            // (only a wave that owns row 0 or has a target fed by source row 0 needs it: one or two members per open column)
             double vD = 0.0;
-            if (vnz && clo == 0) {
+            // the mass point's inputs do not depend on the gather: in flight during it
+            double cD = 0.0;
+            if (own && r < clo) cD = xld(Dp + r);
+            if (virt && clo > 0 && vnz) cD = xld(sP + hb + slot);
+            if (vnz && clo == 0 && __any(own && (r == 0 || (sg0 <= 0 && min(sg2, na) > 0)))) {
                 if (lane < Sact) vD = xld(sP + hb + (size_t)G + (size_t)e * 64 + lane);
                 vD = xwave_sum(vD);
             }
@@ -522,19 +527,19 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
                 if (r == 0 && clo == 0) Dfull += vD;
                 R.lwg[base + r] = make_double2(lwr, igr * Dfull);
                 const int s0 = max(sg0, 0), s2 = min(sg2, na);        // (a record that is not a lottery must not turn into a long loop)
-                // sources two at a time: both sources' loads are in flight before either is used
-                for (int j0 = s0; j0 < s2; j0 += 2) {
-                    double pj[2], Dj[2];
-                    bool on[2];
+                // sources four at a time: all their loads are in flight before the first is used
+                for (int j0 = s0; j0 < s2; j0 += 4) {
+                    double pj[4], Dj[4];
+                    bool on[4];
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
+                    for (int u = 0; u < 4; u++) {
                         const int j = j0 + u;
                         on[u] = j < s2;
                         pj[u] = 0.0; Dj[u] = 0.0;
                         if (on[u]) { pj[u] = R.pol[base + j]; Dj[u] = xld(Dp + j); }
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
+                    for (int u = 0; u < 4; u++) {
                         const int j = j0 + u;
                         if (!on[u]) continue;
                         const bool first = j < sg1;                       // source's upper target is this row
@@ -551,9 +556,6 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
             // ITS rows of the clamped prefix into its virtual row (never combined: everything downstream is linear); while
             // row 0 itself is clamped the old virtual row is carried along.
             {
-                double cD = 0.0;
-                if (own && r < clo) cD = xld(Dp + r);
-                if (virt && clo > 0 && vnz) cD = xld(sP + hb + slot);
                 if (clo > r0) cD = xwave_reduce63(cD);      // wave-uniform: some of this member's rows are clamped (lane 63 takes the sum)
                 if (virt) accD = cD;
             }
