@@ -17,6 +17,7 @@ from .BackwardIteration import BackwardIteration, household_block, household_inp
 from .dual import Dual
 from .ForwardIteration import ForwardIteration
 from .GeneralStructures import JVP, SequenceModel, assemble_full_xMat, vars_of_type
+from ._threads import host_algebra
 
 
 def make_fullFunction(exog_paths, mod: SequenceModel, ss_initial, ss_ending):
@@ -116,6 +117,7 @@ def _lu_solver(J):
     return lambda b: sla.lu_solve(lu, b)
 
 
+@host_algebra
 def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, precond=None,
                 α: float = 1.0, γ: float = 1.5, ε: float = 1e-9, verbose: bool = False, max_inner: int = 10_000,
                 linear_solver: str = "lu"):
@@ -149,6 +151,7 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
     return y
 
 
+@host_algebra
 def NewtonRaphsonHANK(x_0, J̅, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, ε: float = 1e-9,
                       verbose: bool = False, linear_solver: str = "lu"):
     """outer Newton loop (NewtonRaphson.jl:27-46): x ← x − y until ‖y‖ ≤ ε or 100 iterations."""

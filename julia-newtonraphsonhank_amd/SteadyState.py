@@ -18,6 +18,7 @@ import scipy.sparse as sp
 from .Aggregation import Residuals
 from .ForwardIteration import make_endogenous_transition
 from .GeneralStructures import SequenceModel, invariant_dist, var_names, vars_of_type
+from ._threads import host_algebra
 
 
 @dataclass
@@ -111,6 +112,7 @@ class SSAssembler:
         return np.tile(xVals[:, None], (1, T_pad))
 
 
+@host_algebra
 def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vfi_tol=None, vfi: str = "auto") -> SteadyState:
     """Newton–Raphson on the free endogenous variables with step halving (SteadyState.jl:184-233)."""
     asm = SSAssembler(model, ss_spec, vfi_tol, vfi)

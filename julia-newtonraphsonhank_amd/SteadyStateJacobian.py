@@ -14,8 +14,10 @@ import scipy.sparse as sp
 
 from .GeneralStructures import SequenceModel, vars_of_type
 from .NewtonRaphson import LinearizedFunction
+from ._threads import host_algebra
 
 
+@host_algebra
 def getSteadyStateJacobian(ss, model: SequenceModel, chunk: int = 512, drop_tol: float = 0.0, device_batch: int = 256, group=None):
     """n x n sparse Jacobian of F at the constant steady-state path (SteadyStateJacobian.jl:41-65).
     `chunk` unit tangents are pushed per call; only those that move the household inputs (r, w) reach the GPU,
