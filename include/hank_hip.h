@@ -149,8 +149,12 @@ int hank_forward_step_dual(hank_ctx *ctx, const double *policy, const double *dp
 /* ---- steady state ---------------------------------------------------------
  * hank_vfi == the inner fixed point of get_xVals (SteadyState.jl:132-141): value <- model.value_fn(value, xVals, model).Value
  * until max|value_new - value| < tol — checked after EVERY step, like the reference — or max_iter steps (:134 caps at
- * 10 000). The loop is device-resident: the EGM step kernels of hank_backward_step iterate on HBM, only a stop flag
- * comes back per chunk of steps. value_io[G]: in = the starting value (ones in the reference, :132), out = the
+ * 10 000). The loop is device-resident. Where the grid fits the XCD-local schedule it is ONE persistent launch (k_xvfi:
+ * the EGM step of the persistent Float64 sweep with constant prices; every member of the group compares its rows
+ * against tol in Float64 and the group barrier carries the vote, so all members stop in the same step: 4.5 us per step
+ * at 2000x11); otherwise the EGM step kernels of hank_backward_step iterate on HBM and a stop flag comes back per chunk
+ * of steps (23 us per step). Same stopping rule, same step count, same value (tests/test_gpu_steady_state.py).
+ * value_io[G]: in = the starting value (ones in the reference, :132), out = the
  * converged value; policy_out[G] = the policy of the step that produced it; *iters_out = steps taken,
  * *supnorm_out = the last max|difference|. The price Newton and invariant_dist stay on the host. */
 int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t max_iter, double *value_io, double *policy_out,

@@ -394,6 +394,7 @@ static int fetch_device_error(hank_ctx *ctx) {
     HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
     if (e[0] == 0) return ctx->schedule >= 1 ? x_status(ctx) : HANK_OK;
     ctx->primal_done = false;
+    HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));      // reported once: the next call starts clean
     switch (e[0]) {
     case ERR_KNOTS:
         return fail(ctx, HANK_ERR_KNOTS,
@@ -1294,6 +1295,60 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
     const double r = xhh_t[0], w = xhh_t[1], tr = c.n_hh > 2 ? xhh_t[2] : 0.0;
     int hstate[2] = {0, 0};
+    if (use_x_primal(ctx)) {
+        // the whole iteration as ONE persistent launch on the group of XCD 0 (k_xvfi): the vote on convergence rides on the group barrier
+        int rc = x_setup(ctx);
+        if (rc) return rc;
+        XWork &X = ctx->xw;
+        rc = x_serialize_begin(ctx);
+        if (rc) return rc;
+        HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync), s));
+        XVfiArgs va{};
+        va.c = c; va.V0 = V[0]; va.r = r; va.w = w; va.tr = tr; va.tol = tol; va.max_iter = max_iter; va.sy = X.sync; va.st_s = X.st_s;
+        va.err = ctx->d_err; va.Vout = V[1]; va.pol = pol; va.iters = state; va.supnorm = norm;
+        const char *swv = getenv("HANK_XSYNCWAVE");
+        const bool fits = 64 * (c.n_e + 1) <= X.maxt && !(swv && atoi(swv) == 0);
+        const dim3 xblk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e);
+        const size_t lds = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 16) + 64;
+        if (X.maxt == 768) hipLaunchKernelGGL((k_xvfi<768>), dim3(X.grid), xblk, lds, s, va);
+        else hipLaunchKernelGGL((k_xvfi<1024>), dim3(X.grid), xblk, lds, s, va);
+        HIPC(ctx, hipGetLastError());
+        rc = x_serialize_end(ctx);
+        if (rc) return rc;
+        int xs[2] = {0, 0};      // {steps, converged}
+        XSync hsy;
+        HIPC(ctx, hipMemcpyAsync(xs, state, sizeof(xs), hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipMemcpyAsync(&hsy, X.sync, sizeof(XSync), hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipStreamSynchronize(s));
+        X.last_passes = 0;       // (this sync block has been checked here)
+        if (hsy.status[0] == 0) {
+            int e[4];
+            HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
+            if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
+            if (e[0] == ERR_KNOTS)
+                return fail(ctx, HANK_ERR_KNOTS, "knot-vectors must be unique and sorted in increasing order (steady-state value iteration, step %d, "
+                            "productivity state %d, wealth index %d)", xs[0], e[2] + 1, e[3] + 1);
+            if (e[0] == ERR_DOMAIN)
+                return fail(ctx, HANK_ERR_DOMAIN, "DomainError: negative base under a non-integer power (steady-state value iteration, step %d)", xs[0]);
+            double hn = 0.0;
+            HIPC(ctx, hipMemcpyAsync(value_io, V[1], sizeof(double) * G, hipMemcpyDeviceToHost, s));
+            HIPC(ctx, hipMemcpyAsync(policy_out, pol, sizeof(double) * G, hipMemcpyDeviceToHost, s));
+            HIPC(ctx, hipMemcpyAsync(&hn, norm, sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPC(ctx, hipStreamSynchronize(s));
+            if (iters_out) *iters_out = xs[0];
+            if (supnorm_out) *supnorm_out = hn;
+            ctx->stats[5] += xs[0];
+            ctx->errmsg[0] = 0;
+            return HANK_OK;
+        }
+        // the group did not form or a wait timed out: this context continues on the launches (a forced schedule fails loudly)
+        if (!x_fallback_allowed())
+            return fail(ctx, HANK_ERR_SWEEP, "persistent value iteration: %s on XCD %u", hsy.status[0] == XERR_PLACEMENT ? "the group is short of members" : "a wait timed out", hsy.status[1]);
+        rc = to_launch_schedule(ctx);
+        if (rc) return rc;
+        HIPC(ctx, hipMemsetAsync(state, 0, 2 * sizeof(int), s));
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
+    }
     int done = 0;                      // steps enqueued
     const int chunk = 64;              // the stop flag travels to the host once per chunk; converged steps freeze the state
     while (!hstate[0] && done < max_iter) {
@@ -1310,6 +1365,7 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
         HIPC(ctx, hipStreamSynchronize(s));
         int e[4];
         HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
+        if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
         if (e[0] == ERR_KNOTS)
             return fail(ctx, HANK_ERR_KNOTS, "knot-vectors must be unique and sorted in increasing order (steady-state value iteration, step %d, "
                         "productivity state %d, wealth index %d)", hstate[1] + 1, e[2] + 1, e[3] + 1);
@@ -1376,6 +1432,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
     }
     int e[4];
     HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
     if (e[0] == ERR_NONMONO) return fail(ctx, HANK_ERR_NONMONOTONE, "savings policy is not monotone in wealth (productivity state %d, wealth index %d)", e[2] + 1, e[3] + 1);
     // once converged the iteration kernels stop touching the buffers: Dchk holds the last checked iterate
     HIPC(ctx, hipMemcpyAsync(D_io, Dchk, sizeof(double) * G, hipMemcpyDeviceToHost, s));

@@ -438,6 +438,138 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
     }
 }
 
+// ---- the steady state's inner fixed point as ONE launch (hank_vfi; SteadyState.jl:132-141) ----------------------------
+// value <- value_fn(value, xVals).Value until max|value' - value| < tol, on the group of XCD 0 exactly like k_xprimal_back
+// (constant prices, nothing recorded). The group barrier carries the vote: every member publishes, in the same 16-byte
+// store as its episode number, whether ITS rows have converged (compared in Float64 against tol, like k_vfi_check:
+// max < tol over all rows <=> every member's max < tol; a NaN never converges), whether it has seen the device error word
+// set, and its max; every member reads every line, so all of them leave the loop in the same trip.
+struct XVfiArgs {
+    Consts c;
+    const double *V0;           // [G] start value
+    double r, w, tr;
+    double tol;
+    int max_iter;
+    XSync *sy;
+    double *st_s;               // [2][XG][G] knots
+    int *err;
+    double *Vout, *pol;         // [G] the converged value and its policy
+    int *iters;                 // [0] steps taken, [1] 1 = converged
+    double *supnorm;            // max|value' - value| of the last step
+};
+
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xvfi(XVfiArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double xl[];
+    const Consts &c = A.c;
+    const int ne = c.n_e, na = c.n_a, G = c.G;
+    double *Vsh = xl;                                   // [ne][64]
+    double *Pish = Vsh + (size_t)ne * 64;               // [ne*ne]
+    double *ash = Pish + ne * ne;                       // [na]
+    double *redsh = ash + na;                           // [16] per-wave max
+    int *ctl = reinterpret_cast<int *>(redsh + 16);     // [4] group placement, [4..7] the vote's outcome
+    const XGroup g = xgroup_join(A.sy, ctl);
+    if (!g.ok) return;
+    const int x = g.x, cW = g.c;
+    if (x != 0) return;
+    const int Sact = (na + XRW - 1) / XRW;
+    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
+    if (cW >= Sact) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool syncw = wv >= ne;
+    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
+    const int e = syncw ? 0 : wv;
+    const int a = cW * XRW + lane;
+    const bool own = !syncw && lane < XRW && a < na;
+    const size_t pt = (size_t)e * na + (own ? a : 0);
+    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    for (int k = threadIdx.x; k < na; k += blockDim.x) ash[k] = c.a[k];
+    Consts cl = c;
+    cl.a = ash;
+    const double ze = c.z[e], xa = c.a[own ? a : 0];
+    const double rho = 1.0 / (1.0 + A.r);               // same expression as egm_X / k_xrho
+    const size_t hs = (size_t)XG * G;
+    double *const sS = A.st_s;
+    double Vprev = own ? A.V0[pt] : 0.0, V = Vprev, pol = 0.0;
+    if (!syncw) Vsh[e * 64 + lane] = Vprev;
+    __syncthreads();
+    int guess = -1, steps = 0, conv = 0;
+    double gmax = 0.0;
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(&A.sy->flag[x][0][0], 0, 64 * 32 * 4, 0x00020000);     // the group's flag lines
+    unsigned episode = 0;
+    // sequence: X(V_0) | Y -> V_1, vote, X(V_1) | Y -> V_2, vote, X(V_2) | ...: step k is complete after the Y half of trip k
+    for (int i = 0; i <= A.max_iter; i++) {
+        double dmax = 0.0;
+        if (i > 0) {
+            const int cur = (i - 1) & 1;
+            if (own) {
+                XKnots kn;
+                kn.preload(sS + (size_t)cur * hs + (size_t)e * na, a, na, guess);
+                const YOut o = egm_Y(cl, kn, a, e, A.r, A.w, A.tr, A.err, 0, guess);
+                guess = o.ib;
+                V = o.V; pol = o.g;
+                dmax = fabs(V - Vprev);
+                Vprev = V;
+            }
+            if (!syncw) Vsh[e * 64 + lane] = V;
+            // this wave's max (a NaN wins and stays)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const double o2 = __shfl_xor(dmax, off, 64); dmax = (o2 > dmax || !(o2 == o2)) ? o2 : dmax; }
+            if (lane == 0) redsh[wv] = syncw ? 0.0 : dmax;
+            xlds_barrier();
+        }
+        // ---- X half from the value in LDS (it is discarded if the vote below ends the iteration)
+        if (own) {
+            double E;
+            xtile_mix<1, 1>(Vsh + lane, Pish + e, ne, ne, &E);
+            const double bE = E * c.beta;
+            const double ex = -1.0 / c.gamma;
+            if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, 0, e, a);
+            const double cm = pow_crra(bE, ex);
+            sS[(size_t)(i & 1) * hs + pt] = rho * ((cm - (A.w * ze + A.tr)) + xa);
+        }
+        episode++;
+        xbar_arrive(!syncw);
+        if (sync_duty) {
+            // publish {episode, my rows converged, error word seen, -} + my max in ONE 16-byte store, then read everybody's
+            double m = 0.0;
+            for (int k = 0; k < ne; k++) m = (redsh[k] > m || !(redsh[k] == redsh[k])) ? redsh[k] : m;
+            const unsigned mine = (i > 0 && m < A.tol) ? 1u : 0u;
+            const unsigned bad = xldu(reinterpret_cast<const unsigned *>(A.err)) != 0u ? 1u : 0u;
+            if (lane == 0) {
+                xv4u q;
+                q.x = episode; q.y = mine | (bad << 1); q.z = (unsigned)__double2loint(m); q.w = (unsigned)__double2hiint(m);
+                *reinterpret_cast<volatile xv4u *>(&A.sy->flag[x][cW][0]) = q;
+            }
+            xv4u f;
+            f.x = episode; f.y = 1u; f.z = 0u; f.w = 0u;
+            for (unsigned spins = 0;; spins++) {
+                if (lane < Sact) f = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 128, 0, 16);     // sc1: served by the XCD's L2
+                if (__all((int)(f.x - episode) >= 0)) break;
+                if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&A.sy->status[0]) != 0u)) {
+                    if (lane == 0) xfail(A.sy, XERR_TIMEOUT, x);
+                    f.y = 2u;                               // leave the loop: the host reads the status word
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const bool allc = __all((f.y & 1u) != 0u) != 0, anyb = __any((f.y & 2u) != 0u) != 0;
+            double fm = __hiloint2double((int)f.w, (int)f.z);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const double o2 = __shfl_xor(fm, off, 64); fm = (o2 > fm || !(o2 == o2)) ? o2 : fm; }
+            if (lane == 0) { ctl[4] = allc ? 1 : 0; ctl[5] = anyb ? 1 : 0; redsh[15] = fm; }
+        }
+        xlds_barrier();
+        if (i > 0) { steps = i; gmax = redsh[15]; }
+        conv = ctl[4];
+        const int stop = conv | ctl[5];
+        xlds_barrier();                                     // (ctl / redsh are rewritten in the next trip)
+        if (i > 0 && stop) break;
+    }
+    if (own) { A.Vout[pt] = V; A.pol[pt] = pol; }
+    if (cW == 0 && threadIdx.x == 0) { A.iters[0] = steps; A.iters[1] = conv; *A.supnorm = gmax; }
+}
+
 struct XFwdArgs {
     Consts c;
     Record R;                   // pol, seg, clo, lw, ig (k_lottery ran on the policy sequence); lwg and Dseq rows 1..P are written here

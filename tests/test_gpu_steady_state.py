@@ -71,3 +71,47 @@ def test_device_stationary_distribution_matches_the_host(hank):
     assert abs(D_dev.sum() - 1.0) < 1e-14 and D_dev.min() >= 0.0
     assert np.max(np.abs(D_dev - ss.D)) < 1e-10
     assert steps > 25
+
+
+def test_persistent_and_launched_value_iteration_agree(hank, monkeypatch):
+    """hank_vfi as ONE persistent launch (k_xvfi: the vote on convergence rides on the group barrier) against the
+    per-step launches: the same number of steps, the same value and policy (same expressions; both stop on the Float64
+    comparison max|Δvalue| < tol), at a small grid and at the headline grid."""
+    for n_a, n_e in ((50, 2), (2000, 11)):
+        m, ss, _ = ks_setup(n_a, n_e, 100 if n_a == 50 else 300)
+        xv = dict(ss.vars)
+        out = {}
+        for sched in ("launch", "xcd"):
+            monkeypatch.setenv("HANK_SCHEDULE", sched)
+            hb = hank.HouseholdBlock(m.heterogeneity["wealth"].grid, m.heterogeneity["productivity"].grid,
+                                     m.heterogeneity["productivity"].transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+            out[sched] = hb.vfi(np.ones((n_a, n_e)), [xv["r"], xv["w"]], 1e-11)
+            assert hb.stats()["fallbacks"] == 0
+            hb.close()
+        (v0, p0, it0, n0), (v1, p1, it1, n1) = out["launch"], out["xcd"]
+        assert it0 == it1 and n1 < 1e-11 and n0 < 1e-11
+        assert np.max(np.abs(v1 - v0)) <= 1e-13 * np.abs(v0).max()
+        assert np.max(np.abs(p1 - p0)) <= 1e-13 * np.abs(p0).max()
+        # not converged within the cap: both report the cap and the last iterate
+        monkeypatch.setenv("HANK_SCHEDULE", "xcd")
+        hb = hank.HouseholdBlock(m.heterogeneity["wealth"].grid, m.heterogeneity["productivity"].grid,
+                                 m.heterogeneity["productivity"].transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+        v2, p2, it2, n2 = hb.vfi(np.ones((n_a, n_e)), [xv["r"], xv["w"]], 1e-11, 7)
+        assert it2 == 7 and n2 > 1e-11
+        hb.close()
+
+
+def test_persistent_value_iteration_reports_the_reference_errors(hank, monkeypatch):
+    """a wage so negative that consumption turns negative: the DomainError of the reference's power, raised by the
+    persistent loop in the step it happens (it leaves the loop through the vote), not after max_iter steps."""
+    monkeypatch.setenv("HANK_SCHEDULE", "xcd")
+    m, ss, _ = ks_setup(50, 2, 100)
+    hb = hank.HouseholdBlock(m.heterogeneity["wealth"].grid, m.heterogeneity["productivity"].grid,
+                             m.heterogeneity["productivity"].transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+    with pytest.raises((hank.DomainError, hank.KnotsNotSortedError)):
+        hb.vfi(np.ones((50, 2)), [0.01, -50.0], 1e-11)
+    # the context is usable afterwards
+    xv = dict(ss.vars)
+    v, pol, it, nrm = hb.vfi(np.ones((50, 2)), [xv["r"], xv["w"]], 1e-11)
+    assert nrm < 1e-11
+    hb.close()
