@@ -1417,6 +1417,49 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
     HIPC(ctx, hipGetLastError());
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
     int hstate[2] = {0, 0}, done = 0;
+    if (use_x_primal(ctx)) {
+        // the whole power method as ONE persistent launch on the group of XCD 0 (k_xstat)
+        int rc = x_setup(ctx);
+        if (rc) return rc;
+        XWork &X = ctx->xw;
+        rc = x_serialize_begin(ctx);
+        if (rc) return rc;
+        HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync), s));
+        XStatArgs sa{};
+        sa.c = c; sa.R = R; sa.D0 = D[0]; sa.tol = tol; sa.max_iter = max_iter; sa.check_every = check_every; sa.sy = X.sync;
+        sa.st_D = X.st_D; sa.Dout = D[1]; sa.iters = state;
+        const char *swv = getenv("HANK_XSYNCWAVE");
+        const bool fits = 64 * (c.n_e + 1) <= X.maxt && !(swv && atoi(swv) == 0);
+        const dim3 xblk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e);
+        const size_t lds = sizeof(double) * ((size_t)c.n_e * 64 + 16) + 64;
+        if (X.maxt == 768) hipLaunchKernelGGL((k_xstat<768>), dim3(X.grid), xblk, lds, s, sa);
+        else hipLaunchKernelGGL((k_xstat<1024>), dim3(X.grid), xblk, lds, s, sa);
+        HIPC(ctx, hipGetLastError());
+        rc = x_serialize_end(ctx);
+        if (rc) return rc;
+        int xs[2] = {0, 0};
+        XSync hsy;
+        HIPC(ctx, hipMemcpyAsync(xs, state, sizeof(xs), hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipMemcpyAsync(&hsy, X.sync, sizeof(XSync), hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipStreamSynchronize(s));
+        X.last_passes = 0;
+        if (hsy.status[0] == 0) {
+            int e[4];
+            HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
+            if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
+            if (e[0] == ERR_NONMONO) return fail(ctx, HANK_ERR_NONMONOTONE, "savings policy is not monotone in wealth (productivity state %d, wealth index %d)", e[2] + 1, e[3] + 1);
+            HIPC(ctx, hipMemcpyAsync(D_io, D[1], sizeof(double) * G, hipMemcpyDeviceToHost, s));
+            HIPC(ctx, hipStreamSynchronize(s));
+            if (iters_out) *iters_out = xs[0];
+            ctx->errmsg[0] = 0;
+            return HANK_OK;
+        }
+        if (!x_fallback_allowed())
+            return fail(ctx, HANK_ERR_SWEEP, "persistent power method: %s on XCD %u", hsy.status[0] == XERR_PLACEMENT ? "the group is short of members" : "a wait timed out", hsy.status[1]);
+        rc = to_launch_schedule(ctx);
+        if (rc) return rc;
+        HIPC(ctx, hipMemsetAsync(state, 0, 2 * sizeof(int), s));
+    }
     while (!hstate[0] && done < max_iter) {
         // a chunk = several checks; every check compares the iterate with the one check_every steps earlier
         for (int q = 0; q < 16 && done < max_iter; q++) {

@@ -729,6 +729,169 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
 // -> lanes i and i+8 collide, 31 % of the LDS cycles in profiles/r02a; 48 B is conflict-free)
 template <int D> struct XTileT { static constexpr int SL = D == 4 ? 6 : (D == 8 ? 10 : D); };
 
+// ---- the stationary distribution as ONE launch (hank_stationary_dist) ------------------------------------------------
+// D <- Lambda(policy) D on the group of XCD 0 exactly like k_xprimal_fwd with ONE period's lottery record (k_lottery on the
+// steady-state policy: seg, lw, clo), nothing recorded. Every `check_every` iterations each member compares its rows with
+// its copy of the iterate `check_every` steps earlier (registers); the verdict rides on the group barrier as in k_xvfi.
+// A member's virtual row is one of up to `members` parts of row 0: its part must move by less than tol / members, so that
+// the rule is at least as strict as comparing the folded row (|sum| <= sum of |parts|).
+struct XStatArgs {
+    Consts c;
+    Record R;                   // seg, lw, clo of the ONE lottery (period 0 of a private record)
+    const double *D0;           // [G] start
+    double tol;
+    int max_iter, check_every;
+    XSync *sy;
+    double *st_D;               // [2][XG][G + 64*n_e]
+    double *Dout;               // [G] the last iterate, the virtual mass folded into row 0 of its column
+    int *iters;                 // [0] iterations run, [1] 1 = converged
+};
+
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xstat(XStatArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double xl[];
+    const Consts &c = A.c;
+    const Record &R = A.R;
+    const int ne = c.n_e, na = c.n_a, G = c.G;
+    const int GV = G + 64 * ne;
+    double *tile = xl;                                  // [ne][64]
+    double *redsh = tile + (size_t)ne * 64;             // [16] per-wave max
+    int *ctl = reinterpret_cast<int *>(redsh + 16);     // [4] placement, [4..5] the vote's outcome
+    const XGroup g = xgroup_join(A.sy, ctl);
+    if (!g.ok) return;
+    const int x = g.x, cW = g.c;
+    if (x != 0) return;
+    const int Sact = (na + XRW - 1) / XRW;
+    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
+    if (cW >= Sact) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool syncw = wv >= ne;
+    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
+    const int e = syncw ? 0 : wv;
+    const int r0 = cW * XRW, r = r0 + lane;
+    const bool own = !syncw && lane < XRW && r < na;
+    const bool virt = !syncw && lane == 63;
+    const size_t pt = (size_t)e * na + (own ? r : 0);
+    const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;
+    double pr[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[ne * e + k] : 0.0;
+    const size_t hs = (size_t)XG * GV;
+    double *const sP = A.st_D;
+    double Dcur = own ? A.D0[pt] : 0.0;
+    if (own || virt) sP[slot] = Dcur;
+    double Dchk = Dcur;                                 // this lane's entry of the iterate check_every steps back
+    // the lottery does not change: this lane's segments (as a target) and the clamped prefix of its column
+    int sg0 = 0, sg1 = 0, sg2 = 0;
+    if (own) { const int4 q = R.seg[pt]; sg0 = q.x; sg1 = q.y; sg2 = q.z; }
+    const int clo = syncw ? 0 : min(max(R.clo[e], 0), na);
+    bool anyclo = false;
+    for (int k = 0; k < ne; k++) anyclo = anyclo || R.clo[k] > 0;
+    const int s0 = max(sg0, 0), s2 = min(sg2, na);
+    const bool need_vD = anyclo && clo == 0 && __any(own && (sg0 <= 0 && s2 > 0));
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(&A.sy->flag[x][0][0], 0, 64 * 32 * 4, 0x00020000);
+    unsigned episode = 1;
+    xbar_arrive(!syncw);
+    xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
+    int cur = 0, it = 0, conv = 0;
+    bool vnz = false;                                   // the virtual rows hold mass from the first iteration on (if any column is clamped)
+    for (it = 1; it <= A.max_iter; it++) {
+        const size_t hb = (size_t)cur * hs;
+        double accD = 0.0;
+        if (!syncw) {
+            const double *Dp = sP + hb + (size_t)e * na;
+            double cD = 0.0;
+            if (own && r < clo) cD = xld(Dp + r);
+            if (virt && clo > 0 && vnz) cD = xld(sP + hb + slot);
+            double vD = 0.0;
+            if (vnz && need_vD) {
+                if (lane < Sact) vD = xld(sP + hb + (size_t)G + (size_t)e * 64 + lane);
+                vD = xwave_sum(vD);
+            }
+            if (own) {
+                for (int j0 = s0; j0 < s2; j0 += 4) {
+                    double wj[4], Dj[4];
+                    bool on[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + u;
+                        on[u] = j < s2;
+                        wj[u] = 0.0; Dj[u] = 0.0;
+                        if (on[u]) { wj[u] = R.lw[(size_t)e * na + j]; Dj[u] = xld(Dp + j); }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + u;
+                        if (!on[u]) continue;
+                        if (j == 0) Dj[u] += vD;
+                        accD += (j < sg1 ? wj[u] : 1.0 - wj[u]) * Dj[u];
+                    }
+                }
+            }
+            if (clo > r0) cD = xwave_reduce63(cD);
+            if (virt) accD = cD;
+            tile[e * 64 + lane] = accD;
+        }
+        xlds_barrier();
+        vnz = anyclo;
+        const int nxt = cur ^ 1;
+        const bool chk = (it % A.check_every) == 0 || it == A.max_iter;
+        double dmax = 0.0;
+        if (!syncw) {
+            double Dn;
+            xtile_mix_reg<1, 1>(tile + lane, pr, ne, &Dn);
+            if (own || virt) sP[(size_t)nxt * hs + slot] = Dn;
+            Dcur = Dn;
+            if (chk) {
+                if (own) dmax = fabs(Dn - Dchk);
+                else if (virt) dmax = fabs(Dn - Dchk) * (double)Sact;      // one of up to Sact parts of row 0 (see top)
+                Dchk = Dn;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const double o2 = __shfl_xor(dmax, off, 64); dmax = (o2 > dmax || !(o2 == o2)) ? o2 : dmax; }
+            }
+        }
+        if (chk && lane == 0) redsh[wv] = syncw ? 0.0 : dmax;
+        cur = nxt;
+        episode++;
+        xbar_arrive(!syncw);
+        if (sync_duty) {
+            double m = 0.0;
+            if (chk) for (int k = 0; k < ne; k++) m = (redsh[k] > m || !(redsh[k] == redsh[k])) ? redsh[k] : m;
+            if (lane == 0) {
+                xv4u q;
+                q.x = episode; q.y = (chk && m < A.tol) ? 1u : 0u; q.z = 0u; q.w = 0u;
+                *reinterpret_cast<volatile xv4u *>(&A.sy->flag[x][cW][0]) = q;
+            }
+            xv4u f;
+            f.x = episode; f.y = 1u; f.z = 0u; f.w = 0u;
+            for (unsigned spins = 0;; spins++) {
+                if (lane < Sact) f = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 128, 0, 16);
+                if (__all((int)(f.x - episode) >= 0)) break;
+                if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&A.sy->status[0]) != 0u)) {
+                    if (lane == 0) xfail(A.sy, XERR_TIMEOUT, x);
+                    f.y = 2u;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) { ctl[4] = (chk && __all((f.y & 1u) != 0u)) ? 1 : 0; ctl[5] = __any((f.y & 2u) != 0u) ? 1 : 0; }
+        }
+        xlds_barrier();
+        conv = ctl[4];
+        const int stop = conv | ctl[5];
+        xlds_barrier();
+        if (stop) break;
+    }
+    if (it > A.max_iter) it = A.max_iter;
+    // the last iterate; row 0 of a column takes the mass kept on the members' virtual rows (member order fixed, like k_xfix_D)
+    if (own) {
+        double v = Dcur;
+        if (r == 0) for (int m = 0; m < Sact; m++) v += xld(sP + (size_t)cur * hs + (size_t)G + (size_t)e * 64 + m);
+        A.Dout[pt] = v;
+    }
+    if (cW == 0 && threadIdx.x == 0) { A.iters[0] = it; A.iters[1] = conv; }
+}
+
 struct XTanBackArgs {
     Consts c;
     Record R;                   // s, kc, ib, A, B, u, v of the recorded primal

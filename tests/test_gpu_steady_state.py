@@ -115,3 +115,32 @@ def test_persistent_value_iteration_reports_the_reference_errors(hank, monkeypat
     v, pol, it, nrm = hb.vfi(np.ones((50, 2)), [xv["r"], xv["w"]], 1e-11)
     assert nrm < 1e-11
     hb.close()
+
+
+def test_persistent_and_launched_power_method_agree(hank, monkeypatch):
+    """hank_stationary_dist as ONE persistent launch (k_xstat) against one launch per iteration: the same fixed point of the
+    reference's transition matrix to 1e-14, from a uniform start and from a warm start; the cap on the iterations is
+    honoured."""
+    import scipy.sparse as sp
+    for n_a, n_e in ((500, 4), (2000, 11)):
+        m, ss, _ = ks_setup(n_a, n_e, 300)
+        pol = ss.policies["KD"]
+        wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+        Λ_exog = sp.kron(sp.csc_matrix(pdm.transition.T), sp.identity(wd.n, format="csc"), format="csc")
+        Λ = (Λ_exog @ hank.make_endogenous_transition(pol, wd, pdm.n)).tocsc()
+        out = {}
+        for sched in ("launch", "xcd"):
+            monkeypatch.setenv("HANK_SCHEDULE", sched)
+            hb = hank.HouseholdBlock(wd.grid, pdm.grid, pdm.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+            D, steps = hb.stationary_dist(pol)
+            assert np.max(np.abs(Λ @ D - D)) < 1e-14 and abs(D.sum() - 1.0) < 1e-13 and D.min() >= 0.0
+            Dw, steps_w = hb.stationary_dist(pol, D0=D)          # warm start at the fixed point: the first check passes (the
+            # launched loop reports the steps it had enqueued when the host saw the flag: a chunk of 16 checks)
+            assert steps_w <= (50 if sched == "xcd" else 400) and np.max(np.abs(Dw - D)) < 1e-14
+            Dc, steps_c = hb.stationary_dist(pol, max_iter=60)
+            assert steps_c <= 75
+            assert hb.stats()["fallbacks"] == 0
+            out[sched] = (D, steps)
+            hb.close()
+        assert np.max(np.abs(out["xcd"][0] - out["launch"][0])) < 1e-13
+        assert np.max(np.abs(out["xcd"][0] - ss.D)) < 1e-10
