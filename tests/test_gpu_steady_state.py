@@ -77,8 +77,8 @@ def test_persistent_and_launched_value_iteration_agree(hank, monkeypatch):
     """hank_vfi as ONE persistent launch (k_xvfi: the vote on convergence rides on the group barrier) against the
     per-step launches: the same number of steps, the same value and policy (same expressions; both stop on the Float64
     comparison max|Δvalue| < tol), at a small grid and at the headline grid."""
-    for n_a, n_e in ((50, 2), (2000, 11)):
-        m, ss, _ = ks_setup(n_a, n_e, 100 if n_a == 50 else 300)
+    for n_a, n_e, T in ((50, 2, 100), (40, 16, 8), (2000, 11, 300)):      # (40x16: the 1024-thread variants)
+        m, ss, _ = ks_setup(n_a, n_e, T)
         xv = dict(ss.vars)
         out = {}
         for sched in ("launch", "xcd"):
@@ -122,8 +122,8 @@ def test_persistent_and_launched_power_method_agree(hank, monkeypatch):
     reference's transition matrix to 1e-14, from a uniform start and from a warm start; the cap on the iterations is
     honoured."""
     import scipy.sparse as sp
-    for n_a, n_e in ((500, 4), (2000, 11)):
-        m, ss, _ = ks_setup(n_a, n_e, 300)
+    for n_a, n_e, T in ((500, 4, 300), (40, 16, 8), (2000, 11, 300)):
+        m, ss, _ = ks_setup(n_a, n_e, T)
         pol = ss.policies["KD"]
         wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
         Λ_exog = sp.kron(sp.csc_matrix(pdm.transition.T), sp.identity(wd.n, format="csc"), format="csc")
