@@ -189,6 +189,14 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
         except Exception as e:          # noqa: BLE001 - report, do not kill the bench line
             res = {"grid": f"{n_a}x{n_e}", "T": 300, "shock": shock, "error": str(e)[:200]}
         extra["converged_path"].append(res)
+    # the whole RunMain sequence at the headline grid with NOTHING cached: steady state from the YAML guesses (value iteration
+    # and stationary distribution as persistent launches on the device), then J̅ and Newton
+    try:
+        res, _ = solve(2000, 11, 300, 0.01, cold=True)
+        res["yaml_to_converged_path_s"] = round(res["steady_state_s"] + res["wall_to_converged_path_s"], 3)
+    except Exception as e:              # noqa: BLE001
+        res = {"grid": "2000x11", "T": 300, "steady_state": "cold start", "error": str(e)[:200]}
+    extra["converged_path"].append(res)
     return extra
 
 
