@@ -561,10 +561,28 @@ __device__ __forceinline__ double vadd(double a, double b) { return a + b; }
 __device__ __forceinline__ double2 vsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double vsub(double a, double b) { return a - b; }
 
+// XCD-aware block order. The dispatcher deals workgroups to the 8 XCDs round-robin (block p lands on XCD p mod 8), each XCD
+// has its own L2, and neighbouring row blocks gather from overlapping rows: with the natural order every XCD touches every
+// part of the state and a line is fetched by up to 8 L2s. Here the blocks that share an XCD own CONTIGUOUS row ranges
+// (XCD x: logical blocks [start_x, start_x + count_x)), so a state line is fetched once, twice at the 7 seams. A
+// bijection on [0, nb): nothing depends on where a block really runs.
+// Measured at 2000x11: backward sweep -3 % at N=32, -8 % at N=64 and 128, -3 % at N=256; forward sweep -3 % at N=16, nothing
+// at N=32 and +8..12 % (slower) from N=64 on, where one row block's data is many lines already and the natural order
+// spreads the XCDs' requests better over the memory channels: the forward sweep keeps the natural order there.
+#ifndef HANK_XCDMAP_FWD_MAXN
+#define HANK_XCDMAP_FWD_MAXN 32
+#endif
+__device__ __forceinline__ int xcd_contiguous(int p, int nb) {
+    const int x = p & 7, k = p >> 3, q = nb >> 3, rem = nb & 7;
+    return x * q + (x < rem ? x : rem) + k;
+}
+
 template <int RG, typename VT>
 __device__ inline void tan_back_body(const Consts &c, const Record &R, const double *__restrict__ xhh, const VT *__restrict__ dxr,
            const VT *__restrict__ dxw, const VT *__restrict__ dxt, const TanGeom &g, int t, int first, const VT *__restrict__ dsIn,
-           VT *__restrict__ dsOut, VT *__restrict__ dpol, int bidx, int bidy, VT (*dVsh)[16 * 64], double *Pish) {
+           VT *__restrict__ dsOut, VT *__restrict__ dpol, int bidx_phys, int bidy, VT (*dVsh)[16 * 64], double *Pish) {
+    const int nbr_b = (g.nbx + RG - 1) / RG;
+    const int bidx = (bidx_phys < nbr_b) ? xcd_contiguous(bidx_phys, nbr_b) : bidx_phys;
     const int nthr = 64 * c.n_e;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
@@ -698,7 +716,9 @@ k_fused_back(Consts c, Record R, const double *__restrict__ xhh, int *err, int t
 //     tangent), and its aggregate term uses pol[0, e].
 template <int RG, typename VT, bool SS>
 __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanGeom &g, int t, const VT *__restrict__ dDin, VT *__restrict__ dDout,
-          const VT *__restrict__ dpol, VT *__restrict__ aggpart, int bidx, int bidy, int nbx_total, VT (*sh)[16 * 64], double *Pish, VT *red) {
+          const VT *__restrict__ dpol, VT *__restrict__ aggpart, int bidx_phys, int bidy, int nbx_total, VT (*sh)[16 * 64], double *Pish, VT *red) {
+    const int nbr_f = (g.nbx + RG - 1) / RG;            // regular blocks; the mass-point blocks behind them keep their place
+    const int bidx = (g.N * (int)(sizeof(VT) / 8) <= HANK_XCDMAP_FWD_MAXN && bidx_phys < nbr_f) ? xcd_contiguous(bidx_phys, nbr_f) : bidx_phys;
     const int nthr = 64 * c.n_e;
     const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
