@@ -112,6 +112,8 @@ if __name__ == "__main__":
             os.environ["HANK_XRUNAHEAD"] = str(mask)
             print("HANK_XRUNAHEAD =", mask, flush=True)
             timing(2000, 11, 300, [1, 32], scheds=("xcd",))
+    if what == "tl2":     # geometry knobs (HANK_RG_B / HANK_RG_F / HANK_FWD_SS in the environment) at the two widths that matter
+        timing(2000, 11, 300, [32, 64], scheds=("launch",))
     if what == "tl":      # the launched sweeps alone
         timing(2000, 11, 300, [16, 32, 64, 128, 256], scheds=("launch",))
     if what == "tx":      # the persistent sweeps alone, the widths that matter
