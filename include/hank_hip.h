@@ -164,7 +164,7 @@ int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t max_iter, d
  * the forward step of the hot path (Young lottery of `policy`[G] + exogenous transition), until two iterates
  * `check_every` steps apart differ by less than `tol` (max norm) or `max_iter` steps. This is the iteration the host's
  * invariant_dist uses for chains too large for the reference's direct solve (ForwardIteration.jl:436-442); same fixed
- * point. Where the grid fits the XCD-local schedule the whole iteration is ONE persistent launch (k_xstat: 3.4 us per
+ * point. Where the grid fits the XCD-local schedule the whole iteration is ONE persistent launch (k_xstat: 3.0 us per
  * iteration at 2000x11, the verdict of every check rides on the group barrier), otherwise one launch per iteration and a
  * stop flag per chunk of checks (*iters_out then counts the iterations enqueued when the host saw the flag).
  * D_io[G]: in = start (any positive vector), out = the last iterate (NOT normalised). */

@@ -1295,7 +1295,8 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
     const double r = xhh_t[0], w = xhh_t[1], tr = c.n_hh > 2 ? xhh_t[2] : 0.0;
     int hstate[2] = {0, 0};
-    if (use_x_primal(ctx)) {
+    const char *xve = getenv("HANK_XVFI");            // dev knob: 0 = per-step launches
+    if (use_x_primal(ctx) && !(xve && atoi(xve) == 0)) {
         // the whole iteration as ONE persistent launch on the group of XCD 0 (k_xvfi): the vote on convergence rides on the group barrier
         int rc = x_setup(ctx);
         if (rc) return rc;
@@ -1417,7 +1418,8 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
     HIPC(ctx, hipGetLastError());
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
     int hstate[2] = {0, 0}, done = 0;
-    if (use_x_primal(ctx)) {
+    const char *xse = getenv("HANK_XSTAT");           // dev knob: 0 = one launch per iteration
+    if (use_x_primal(ctx) && !(xse && atoi(xse) == 0)) {
         // the whole power method as ONE persistent launch on the group of XCD 0 (k_xstat)
         int rc = x_setup(ctx);
         if (rc) return rc;

@@ -874,7 +874,8 @@ __global__ void __launch_bounds__(MAXT) k_xstat(XStatArgs A) {
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (lane == 0) { ctl[4] = (chk && __all((f.y & 1u) != 0u)) ? 1 : 0; ctl[5] = __any((f.y & 2u) != 0u) ? 1 : 0; }
+            const bool allc = __all((f.y & 1u) != 0u) != 0, anyb = __any((f.y & 2u) != 0u) != 0;      // (every lane votes: not inside the lane-0 branch)
+            if (lane == 0) { ctl[4] = (chk && allc) ? 1 : 0; ctl[5] = anyb ? 1 : 0; }
         }
         xlds_barrier();
         conv = ctl[4];

@@ -144,3 +144,27 @@ def test_persistent_and_launched_power_method_agree(hank, monkeypatch):
             hb.close()
         assert np.max(np.abs(out["xcd"][0] - out["launch"][0])) < 1e-13
         assert np.max(np.abs(out["xcd"][0] - ss.D)) < 1e-10
+
+
+def test_power_method_stops_only_when_every_member_has_converged(hank, monkeypatch):
+    """far from the solution (r = 4 %: every household saves, the mass ends on the top grid point) the bottom of the grid
+    settles hundreds of iterations before the top. The persistent launch must keep going until EVERY member's rows pass the
+    rule — the first version of its vote looked at member 0 only and stopped at 500 of 800 iterations with |ΛD − D| = 6e-9,
+    which the steady state's price Newton then paid for with twice as many inner solves."""
+    import scipy.sparse as sp
+    m, ss, _ = ks_setup(2000, 11, 300)
+    wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    Λ_exog = sp.kron(sp.csc_matrix(pdm.transition.T), sp.identity(wd.n, format="csc"), format="csc")
+    out = {}
+    for sched in ("launch", "xcd"):
+        monkeypatch.setenv("HANK_SCHEDULE", sched)
+        hb = hank.HouseholdBlock(wd.grid, pdm.grid, pdm.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+        v, pol, it, nrm = hb.vfi(np.ones((2000, 11)), [0.04, 1.0], 1e-11)
+        Λ = (Λ_exog @ hank.make_endogenous_transition(pol, wd, pdm.n)).tocsc()
+        D, steps = hb.stationary_dist(pol)
+        assert np.max(np.abs(Λ @ D - D)) < 1e-14, (sched, steps)
+        assert D.reshape(2000, 11, order="F")[-1].sum() > 0.999          # the mass sits on the top grid point
+        out[sched] = (D, steps)
+        hb.close()
+    assert out["xcd"][1] == 800 and out["launch"][1] == 800               # the rule first holds at the 32nd check
+    assert np.max(np.abs(out["xcd"][0] - out["launch"][0])) < 1e-13
