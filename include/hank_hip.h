@@ -16,8 +16,8 @@
  *     (3 for the one-asset HANK family: (r_t, w_t, tr_t)); hank_n_hh() tells.
  *   - tangent batches are Julia-natural: dxhh is (n_hh, P, N) column-major, dagg is (P, N).
  *   - the caller owns every host buffer; the library copies in/out and retains no pointer past a
- *     call; the context owns all device memory. A context is bound to the HIP device that was
- *     current at hank_create, is not thread-safe, and host-pointer calls are synchronous on return.
+ *     call; the context owns all device memory. A context is bound to ONE HIP device (hank_create:
+ *     the current one; hank_create_on: the one named), is not thread-safe, and host-pointer calls are synchronous on return.
  *   - every function returns a status (0 = ok). Julia exceptions on this path become codes:
  *     hank_last_error() carries the message the shim turns back into error(...).
  *
@@ -47,8 +47,9 @@ enum {
     HANK_ERR_NONMONOTONE = 6, /* savings policy not monotone in wealth (cannot happen when the
                                  knots check passes; guards the segmented Young push-forward)      */
     HANK_ERR_NOMEM = 7,
-    HANK_ERR_SWEEP = 8        /* a persistent sweep could not form its workgroup groups or a wait in it timed out
+    HANK_ERR_SWEEP = 8,       /* a persistent sweep could not form its workgroup groups or a wait in it timed out
                                  (host-pointer entries fall back to the per-period launches by themselves)     */
+    HANK_ERR_LAUNCH = 9       /* a kernel launch / graph / copy was refused by the HIP runtime (the message names it)   */
 };
 
 /* value-function families resolved from the YAML `function:` name (KrusellSmith.yaml:86,
@@ -73,7 +74,13 @@ typedef struct {
 } hank_model;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
-int hank_create(const hank_model *model, hank_ctx **out);
+int hank_create(const hank_model *model, hank_ctx **out);   /* on the calling thread's current HIP device */
+/* The same on HIP device `device` (0 .. hipGetDeviceCount-1). The reference has no notion of a device: `JVP(func, primal,
+ * tangent)` (GeneralStructures.jl:542-550) is linear in `tangent`, so the columns of a tangent batch (the Jacobian
+ * columns of SteadyStateJacobian.jl:240-243, ForwardDiff's chunks) shard over one context per GPU of a node; every entry
+ * point makes its context's device current for the call and restores the caller's, so ONE host thread can keep all of a
+ * node's contexts busy through the *_dev entries ("one process, eight GPUs"). */
+int hank_create_on(const hank_model *model, int32_t device, hank_ctx **out);
 int hank_destroy(hank_ctx *ctx);
 const char *hank_last_error(const hank_ctx *ctx); /* never NULL; "" when the last call succeeded  */
 int hank_n_hh(const hank_ctx *ctx);               /* household inputs per period (KS: 2)          */

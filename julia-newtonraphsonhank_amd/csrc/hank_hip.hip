@@ -81,6 +81,7 @@ struct XWork {
     double *Dvirt = nullptr, *aggpart = nullptr, *rho = nullptr;
     int *srcB = nullptr, *srcF = nullptr;     // [P][Sact] source-member ranges of the tangent sweeps at the recorded primal
     int *rdrB = nullptr, *rdrF = nullptr;     // [P][Sact] the inverse: which members read a member's rows
+    int2 *pubB = nullptr;                     // [P][Sact][16] backward slab sweep: which rows a member stores to L2 (k_wpub_back)
     int lds_max = 65536;
     bool src_valid = false;
     std::list<XTan> tans;           // most recently used first
@@ -140,23 +141,33 @@ static int fail(hank_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
+static int hip_status(hipError_t e) {
+    if (e == hipErrorOutOfMemory) return HANK_ERR_NOMEM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNotInitialized || e == hipErrorInsufficientDriver) return HANK_ERR_NO_DEVICE;
+    return HANK_ERR_LAUNCH;
+}
 #define HIPC(ctx, call)                                                                         \
     do {                                                                                        \
         hipError_t e_ = (call);                                                                 \
         if (e_ != hipSuccess)                                                                   \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? HANK_ERR_NOMEM : HANK_ERR_NO_DEVICE,   \
+            return fail(ctx, hip_status(e_),                                                   \
                         "HIP error %d (%s) at %s:%d: %s", (int)e_, hipGetErrorString(e_),       \
                         __FILE__, __LINE__, #call);                                             \
     } while (0)
 
-// a context is bound to the HIP device that was current at hank_create: calling it with another device current would
-// launch on that other device with this one's pointers
-#define ENTER(ctx)                                                                                                    \
-    do {                                                                                                              \
-        int dev_ = -1;                                                                                                \
-        if ((ctx) && hipGetDevice(&dev_) == hipSuccess && dev_ != (ctx)->device)                                      \
-            return fail(ctx, HANK_ERR_BAD_ARG, "context is bound to HIP device %d, the current device is %d", (ctx)->device, dev_); \
-    } while (0)
+// a context belongs to ONE HIP device (hank_create: the current one; hank_create_on: the one named). Every entry point
+// makes that device current for the duration of the call and restores the caller's, so one host thread can drive one
+// context per GPU of a node (GeneralStructures.jl:542-550 has no notion of a device: the shim owns the placement).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const hank_ctx *ctx);
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+DeviceGuard::DeviceGuard(const hank_ctx *ctx) {
+    if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+}
+#define ENTER(ctx) DeviceGuard dev_guard_(ctx)
 
 template <typename T>
 static hipError_t dmalloc(T **p, size_t count) {
@@ -363,25 +374,32 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     geom(VB, w.g); geom(VF, w.gf);
     w.nbx = w.g.nbx; w.nbxf = w.gf.nbx;
     const size_t GV = (size_t)(c.n_a + KV) * c.n_e;   // dD state carries KV virtual rows per column
-    HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
-    HIPC(ctx, dmalloc(&w.dxr, P * N));
-    HIPC(ctx, dmalloc(&w.dxw, P * N));
-    HIPC(ctx, dmalloc(&w.dxt, P * N));
-    for (int k = 0; k < 2; k++) {
-        HIPC(ctx, dmalloc(&w.ds[k], G * N));
-        HIPC(ctx, dmalloc(&w.dD[k], GV * N));
-    }
-    HIPC(ctx, dmalloc(&w.dpol, P * G * N));
     // forward kernel form: source-stationary for 16-lane groups (N = 18..32: forward sweep 3.42 -> 3.05 ms at N=32
     // with 2 row groups), target-stationary gather otherwise (equal within 2 % at N = 16, 64, 256)
     const char *se = getenv("HANK_FWD_SS");   // dev knob
     w.gf.ss = se ? atoi(se) : (w.gf.NC == 16 ? 1 : 0);
     const int RGB = tan_rg(w.g.N, 0), RGF = tan_rg(w.gf.N, 1, w.gf.ss);
     const unsigned nbf = (w.nbxf + RGF - 1) / RGF + KV;   // forward blocks: regular + mass-point
-    HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
-    HIPC(ctx, dmalloc(&w.dagg, P * N));
-    HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
     w.VB = VB; w.VF = VF; w.RGB = RGB; w.RGF = RGF; w.nbf = nbf;
+    // a failed allocation must not leave a half-built entry in the cache: a retry with this N would find it, return
+    // HANK_OK and launch on null pointers
+    auto alloc = [&]() -> int {
+        HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
+        HIPC(ctx, dmalloc(&w.dxr, P * N));
+        HIPC(ctx, dmalloc(&w.dxw, P * N));
+        HIPC(ctx, dmalloc(&w.dxt, P * N));
+        for (int k = 0; k < 2; k++) {
+            HIPC(ctx, dmalloc(&w.ds[k], G * N));
+            HIPC(ctx, dmalloc(&w.dD[k], GV * N));
+        }
+        HIPC(ctx, dmalloc(&w.dpol, P * G * N));
+        HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
+        HIPC(ctx, dmalloc(&w.dagg, P * N));
+        HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
+        return HANK_OK;
+    };
+    const int rc = alloc();
+    if (rc) { free_tanwork(w); ctx->tws.pop_front(); ctx->tw = ctx->tws.empty() ? nullptr : &ctx->tws.front(); (void)hipGetLastError(); return rc; }
     return HANK_OK;
 }
 
@@ -426,10 +444,23 @@ static int fetch_device_error(hank_ctx *ctx) {
 static std::mutex g_xmutex;
 static hipEvent_t g_xlast[64] = {};
 
-static bool x_supported(const hank_ctx *ctx, int cus) {
+// dynamic LDS of the persistent kernels (the expressions the kernels carve up): it grows with the horizon P
+static size_t x_lds_primal_back(const Consts &c) { return sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * (size_t)c.P) + 64; }
+static size_t x_lds_primal_fwd(const Consts &c) { return sizeof(double) * ((size_t)c.n_e * 64) + sizeof(int) * (size_t)c.P * c.n_e + 64; }
+static size_t x_lds_tan_back(const Consts &c, int D) {
+    const int SLt = D == 4 ? 6 : D;      // XTileT<D>::SL
+    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + c.P + 1 + 3 * (size_t)c.P * D) + sizeof(int) * (size_t)c.P + 64;
+}
+static size_t x_lds_tan_fwd(const Consts &c, int D) {
+    const int SLt = D == 4 ? 6 : D;
+    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * ((size_t)c.P * c.n_e + c.P) + 64;
+}
+// the grid fits the XCD-local schedule: a 63-row slab per CU of an XCD, and the Float64 sweeps' LDS (which holds the
+// per-period inputs of the WHOLE horizon) fits a workgroup
+static bool x_supported(const hank_ctx *ctx, int cus, size_t lds_max) {
     const Consts &c = ctx->c;
     const int Sact = (c.n_a + XRW - 1) / XRW;
-    return cus >= XG && Sact <= cus / XG && c.n_e <= 16;
+    return cus >= XG && Sact <= cus / XG && c.n_e <= 16 && std::max(x_lds_primal_back(c), x_lds_primal_fwd(c)) <= lds_max;
 }
 
 static void x_free_tan(XTan &w) {
@@ -446,7 +477,7 @@ static void x_free(hank_ctx *ctx) {
     ctx->xcur = nullptr;
     (void)hipFree(X.sync); (void)hipFree(X.st_s); (void)hipFree(X.st_ds); (void)hipFree(X.st_D); (void)hipFree(X.st_dD);
     (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart); (void)hipFree(X.rho); (void)hipFree(X.srcB); (void)hipFree(X.srcF);
-    (void)hipFree(X.rdrB); (void)hipFree(X.rdrF);
+    (void)hipFree(X.rdrB); (void)hipFree(X.rdrF); (void)hipFree(X.pubB);
     X = XWork();
 }
 
@@ -463,6 +494,7 @@ static int x_setup(hank_ctx *ctx) {
     X.dmax = X.maxt == 768 ? XD_MAX : 2;
     const size_t G = c.G, GV = G + 64 * (size_t)c.n_e, P = c.P;
     HIPC(ctx, dmalloc(&X.sync, (size_t)2 + 2 * XPASS_MAX));
+    HIPC(ctx, hipMemset(X.sync, 0, sizeof(XSync) * ((size_t)2 + 2 * XPASS_MAX)));      // x_status reads blocks 0, 1 also when the launches recorded the primal
     HIPC(ctx, dmalloc(&X.st_s, 2 * XG * G));
     HIPC(ctx, dmalloc(&X.st_ds, 2 * XG * G * X.dmax));
     HIPC(ctx, dmalloc(&X.st_D, 2 * XG * GV));
@@ -475,6 +507,7 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.srcF, P * X.Sact));
     HIPC(ctx, dmalloc(&X.rdrB, P * X.Sact));
     HIPC(ctx, dmalloc(&X.rdrF, P * X.Sact));
+    HIPC(ctx, dmalloc(&X.pubB, P * X.Sact * 16));
     X.lds_max = (int)prop.sharedMemPerBlock;
     HIPC(ctx, hipMemset(X.Dvirt, 0, sizeof(double) * P * c.n_e * 64));
     X.ready = true;
@@ -494,13 +527,13 @@ static void w_plan(const hank_ctx *ctx, int n, int &DW, int &NW) {
     else if (n <= 16) { DW = 2; NW = 1; }
     else if (n <= 32) { DW = 2; NW = 2; }
     else if (n <= 64) { DW = 4; NW = 2; }
-    else if (n <= 128) { DW = 4; NW = 4; }
-    else { DW = 4; NW = 8; }
-    if (w_nec(ctx) > 12 && DW == 4) { DW = 2; NW = std::min(8, NW * 2); }     // 16 columns x 4 directions do not fit the registers
+    else { DW = 4; NW = 4; }
+    if (w_nec(ctx) > 12 && DW == 4) { DW = 2; NW = std::min(7, NW * 2); }     // 16 columns x 4 directions do not fit the registers
     if (const char *e = getenv("HANK_W_DW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) DW = v; }
-    if (const char *e = getenv("HANK_W_NW")) { const int v = atoi(e); if (v >= 1 && v <= 8) NW = v; }
-    // the forward sweep's LDS (staged sources per wave) must fit
-    while (NW > 1 && (int)wfwd_lds(w_nec(ctx), DW, NW) > ctx->xw.lds_max) NW--;
+    if (const char *e = getenv("HANK_W_NW")) { const int v = atoi(e); if (v >= 1 && v <= 7) NW = v; }      // + the loader wave: 8 waves, two per SIMD
+    // the strips of the waves' own rows and the coefficient ring must fit the CU's LDS
+    const int ne = ctx->c.n_e, NEC = w_nec(ctx);
+    while (NW > 1 && (int)std::max(wfwd_lds(ne, NEC, DW, NW), wback_lds(ne, NEC, DW, NW)) > ctx->xw.lds_max) NW--;
 }
 
 // tangent buffers for a batch of N directions, from a small most-recently-used cache (Jacobian assembly at N = 256
@@ -605,8 +638,13 @@ template <int DW>
 static void w_launch_nec(int NEC, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const WTanBackArgs &ab, const WTanFwdArgs &af) {
 #define WL(NV)                                                                                       \
     do {                                                                                             \
-        if (back) hipLaunchKernelGGL((k_wtan_back<DW, NV, 512>), grd, blk, lds, s, ab);              \
-        else hipLaunchKernelGGL((k_wtan_fwd<DW, NV, 512>), grd, blk, lds, s, af);                    \
+        if (blk.x <= 256) {          /* one wave per SIMD: the whole register file */                \
+            if (back) hipLaunchKernelGGL((k_wtan_back<DW, NV, 256>), grd, blk, lds, s, ab);          \
+            else hipLaunchKernelGGL((k_wtan_fwd<DW, NV, 256>), grd, blk, lds, s, af);                \
+        } else {                                                                                     \
+            if (back) hipLaunchKernelGGL((k_wtan_back<DW, NV, 512>), grd, blk, lds, s, ab);          \
+            else hipLaunchKernelGGL((k_wtan_fwd<DW, NV, 512>), grd, blk, lds, s, af);                \
+        }                                                                                            \
     } while (0)
     if (NEC == 4) WL(4);
     else if (NEC == 8) WL(8);
@@ -654,8 +692,7 @@ static int x_run_primal(hank_ctx *ctx) {
     ab.err = ctx->d_err; ab.R = ctx->R;
     XFwdArgs af{};
     af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.sy = X.sync + 1; af.st_D = X.st_D; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart;
-    const size_t ldsb = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * P) + 64;
-    const size_t ldsf = sizeof(double) * ((size_t)c.n_e * 64) + sizeof(int) * P * c.n_e + 64;
+    const size_t ldsb = x_lds_primal_back(c), ldsf = x_lds_primal_fwd(c);
     HIPC(ctx, hipEventRecord(ctx->ev[0], s));
     if (X.maxt == 768) x_launch_primal<768>(true, grd, blk, ldsb, s, ab, af);
     else x_launch_primal<1024>(true, grd, blk, ldsb, s, ab, af);
@@ -701,6 +738,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
         const unsigned nr = (unsigned)((P * X.Sact + 255) / 256);
         hipLaunchKernelGGL(k_wrdr, dim3(nr), dim3(256), 0, s, X.srcB, (int)P, X.Sact, X.rdrB);
         hipLaunchKernelGGL(k_wrdr, dim3(nr), dim3(256), 0, s, X.srcF, (int)P, X.Sact, X.rdrF);
+        hipLaunchKernelGGL(k_wpub_back, dim3((unsigned)P), dim3(256), 0, s, c, ctx->R, X.Sact, X.pubB);
         X.src_valid = true;
     }
     if (w->slab) {
@@ -710,15 +748,18 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
         WTanBackArgs ab{};
         ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st = w->st_b;
         ab.src = neigh ? X.srcB : nullptr; ab.rdr = neigh ? X.rdrB : nullptr;
+        const char *ar = getenv("HANK_W_ALLROWS");   // dev knob: 1 = every row goes through L2 (no halo selection)
+        const bool allrows = ar && atoi(ar) != 0;
+        ab.pub = allrows ? nullptr : X.pubB;
         WTanFwdArgs af{};
         af.c = c; af.R = ctx->R; af.st = w->st_f; af.daggpart = w->daggpart;
-        af.src = neigh ? X.srcF : nullptr; af.rdr = neigh ? X.rdrF : nullptr;
+        af.src = neigh ? X.srcF : nullptr; af.rdr = neigh ? X.rdrF : nullptr; af.all_rows = allrows ? 1 : 0;
         const dim3 grd(X.grid);
         HIPC(ctx, hipEventRecord(ctx->ev[3], s));
         for (int p = 0; p < np; p++) {
             const XPass &ps = w->passes[p];
             ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.NW = ps.NW; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
-            w_launch(ps.D, NEC, true, grd, dim3(64 * ps.NW), wback_lds(NEC, ps.D, ps.NW), s, ab, af);
+            w_launch(ps.D, NEC, true, grd, dim3(64 * (ps.NW + 1)), wback_lds(c.n_e, NEC, ps.D, ps.NW), s, ab, af);
         }
         HIPC(ctx, hipEventRecord(ctx->ev[4], s));
         HIPC(ctx, hipEventRecord(ctx->ev[7], s));
@@ -726,7 +767,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
             const XPass &ps = w->passes[p];
             const int W = ps.groups * ps.NW * ps.D;
             af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.NW = ps.NW; af.N = ps.N; af.W = W; af.dpol = w->dpol + ps.dpol_off;
-            w_launch(ps.D, NEC, false, grd, dim3(64 * ps.NW), wfwd_lds(NEC, ps.D, ps.NW), s, ab, af);
+            w_launch(ps.D, NEC, false, grd, dim3(64 * (ps.NW + 1)), wfwd_lds(c.n_e, NEC, ps.D, ps.NW), s, ab, af);
             if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
             hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, X.Sact, W, w->dagg_pass);
             hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, W, ps.n0, ps.N, w->dagg_cm);
@@ -762,8 +803,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
-        const int SLt = ps.D == 4 ? 6 : ps.D;      // XTileT<D>::SL
-        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + P + 1 + 3 * P * ps.D) + sizeof(int) * P + 64;
+        const size_t lds = x_lds_tan_back(c, ps.D);
         if (X.maxt == 768) x_launch_tan<768>(ps.D, true, grd, blk, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, true, grd, blk, lds, s, ab, af);
     }
@@ -773,8 +813,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.N = ps.N; af.dpol = w->dpol + ps.dpol_off;
-        const int SLt = ps.D == 4 ? 6 : ps.D;
-        const size_t lds = sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * (P * c.n_e + P) + 64;
+        const size_t lds = x_lds_tan_fwd(c, ps.D);
         if (X.maxt == 768) x_launch_tan<768>(ps.D, false, grd, blkF, lds, s, ab, af);
         else x_launch_tan<1024>(ps.D, false, grd, blkF, lds, s, ab, af);
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
@@ -830,6 +869,13 @@ int hank_device_available(void) {
 int hank_n_hh(const hank_ctx *ctx) { return ctx ? ctx->c.n_hh : 0; }
 
 int hank_create(const hank_model *m, hank_ctx **out) {
+    int dev = 0;
+    if (out) *out = nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return HANK_ERR_NO_DEVICE;
+    return hank_create_on(m, dev, out);
+}
+
+int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     if (!m || !out) return HANK_ERR_BAD_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -837,6 +883,9 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     hank_ctx *ctx = new (std::nothrow) hank_ctx();
     if (!ctx) return HANK_ERR_NOMEM;
     *out = ctx;  // returned even on failure so the caller can read hank_last_error, then destroy
+    if (device < 0 || device >= ndev) return fail(ctx, HANK_ERR_BAD_ARG, "device %d: the process sees %d HIP device(s)", device, ndev);
+    ctx->device = device;
+    ENTER(ctx);
     if (m->n_a < 2 || m->n_e < 1 || m->n_e > 16 || m->T < 2)
         return fail(ctx, HANK_ERR_BAD_ARG, "bad shape: n_a=%d (>=2), n_e=%d (1..16), T=%d (>=2)", m->n_a, m->n_e, m->T);
     if (m->value_fn_id != HANK_VF_KRUSELL_SMITH && m->value_fn_id != HANK_VF_ONE_ASSET_HANK)
@@ -844,7 +893,6 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     if (!m->a_grid || !m->z_grid || !m->Pi) return fail(ctx, HANK_ERR_BAD_ARG, "null grid pointer");
     for (int i = 1; i < m->n_a; i++)
         if (!(m->a_grid[i] > m->a_grid[i - 1])) return fail(ctx, HANK_ERR_BAD_ARG, "wealth grid must be strictly increasing (index %d)", i + 1);
-    HIPC(ctx, hipGetDevice(&ctx->device));
     hipDeviceProp_t prop;
     HIPC(ctx, hipGetDeviceProperties(&prop, ctx->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -893,11 +941,12 @@ int hank_create(const hank_model *m, hank_ctx **out) {
     // XCD-local persistent sweeps, the dual pass (hank_primal_jvp) and wide batches as per-period launches; both
     // read and write the same record. HANK_SCHEDULE=launch|xcd forces one implementation for everything (A-B, tests).
     const char *se = getenv("HANK_SCHEDULE");
-    ctx->schedule = x_supported(ctx, prop.multiProcessorCount) ? 2 : 0;
+    ctx->schedule = x_supported(ctx, prop.multiProcessorCount, prop.sharedMemPerBlock) ? 2 : 0;
     if (se && strcmp(se, "launch") == 0) ctx->schedule = 0;
     if (se && strcmp(se, "xcd") == 0) {
         if (ctx->schedule == 0)
-            return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=xcd: n_a=%d needs %d workgroups per XCD, the device has %d", c.n_a, (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG);
+            return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=xcd: n_a=%d needs %d workgroups per XCD (the device has %d) and %zu bytes of LDS per workgroup (it has %zu)", c.n_a,
+                        (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG, std::max(x_lds_primal_back(c), x_lds_primal_fwd(c)), (size_t)prop.sharedMemPerBlock);
         ctx->schedule = 1;
     }
     if (const char *xm = getenv("HANK_XJVP_MAX")) ctx->xjvp_max = atoi(xm);
@@ -911,6 +960,7 @@ int hank_create(const hank_model *m, hank_ctx **out) {
 
 int hank_destroy(hank_ctx *ctx) {
     if (!ctx) return HANK_OK;
+    ENTER(ctx);
     if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     for (TanWork &t : ctx->tws) free_tanwork(t);
@@ -937,6 +987,7 @@ int hank_destroy(hank_ctx *ctx) {
 
 int hank_set_stream(hank_ctx *ctx, void *hip_stream) {
     if (!ctx) return HANK_ERR_BAD_ARG;
+    ENTER(ctx);
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     if (next != ctx->stream) {      // what is still queued on the old stream (and on the side stream) happens before the new one's work
         HIPC(ctx, join_side(ctx));
@@ -949,6 +1000,7 @@ int hank_set_stream(hank_ctx *ctx, void *hip_stream) {
 
 int hank_sync(hank_ctx *ctx) {
     if (!ctx) return HANK_ERR_BAD_ARG;
+    ENTER(ctx);
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return HANK_OK;
@@ -1025,8 +1077,17 @@ static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcp
     return HANK_OK;
 }
 static bool use_x_primal(const hank_ctx *ctx) { return ctx->schedule >= 1; }
-static bool use_x_jvp(const hank_ctx *ctx, int N) { return ctx->schedule == 1 || (ctx->schedule == 2 && N <= ctx->xjvp_max); }
-static bool use_x_fused(const hank_ctx *ctx) { return ctx->schedule == 1; }      // auto: the dual-sweep launches hide the primal chain
+// the persistent tangent sweeps' LDS grows with the horizon too (the group's dr/dw/dtr of every period): a long horizon goes
+// to the per-period launches, which take any T
+static bool x_tan_fits(const hank_ctx *ctx, int N) {
+    const XWork &X = ctx->xw;
+    if (x_use_slab()) return true;        // (the slab sweeps size their waves to the LDS: w_plan)
+    int D = 1;
+    while (XG * D < N && D < X.dmax) D *= 2;
+    return std::max(x_lds_tan_back(ctx->c, D), x_lds_tan_fwd(ctx->c, D)) <= (size_t)X.lds_max;
+}
+static bool use_x_jvp(const hank_ctx *ctx, int N) { return (ctx->schedule == 1 || (ctx->schedule == 2 && N <= ctx->xjvp_max)) && x_tan_fits(ctx, N); }
+static bool use_x_fused(const hank_ctx *ctx, int N) { return ctx->schedule == 1 && x_tan_fits(ctx, N); }      // auto: the dual-sweep launches hide the primal chain
 
 // a sweep could not form its groups (or timed out): this context continues on the per-period launches
 static int to_launch_schedule(hank_ctx *ctx) {
@@ -1189,7 +1250,7 @@ int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh
     ENTER(ctx);
     if (!ctx || !d_xhh || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
-    if (use_x_fused(ctx)) return x_dual(ctx, d_xhh, d_dxhh, hipMemcpyDeviceToDevice, N, d_agg_out, d_dagg_out);
+    if (use_x_fused(ctx, N)) return x_dual(ctx, d_xhh, d_dxhh, hipMemcpyDeviceToDevice, N, d_agg_out, d_dagg_out);
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
     const size_t P = ctx->c.P;
@@ -1212,7 +1273,7 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
         if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
     int rc = HANK_OK;
     const double *d_dagg = nullptr;
-    if (use_x_fused(ctx)) {
+    if (use_x_fused(ctx, N)) {
         rc = x_dual(ctx, xhh, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
         if (rc) return rc;
         rc = fetch_device_error(ctx);
@@ -1259,6 +1320,7 @@ int hank_stats(hank_ctx *ctx, int64_t out[8]) {
 
 int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]) {
     if (!ctx || !out_ms) return HANK_ERR_BAD_ARG;
+    ENTER(ctx);
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     int a[6] = {0, 6, 3, 7, 8, 9}, b[6] = {1, 2, 4, 5, 9, 10};
@@ -1276,6 +1338,7 @@ int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]) {
 
 int hank_get_policy_seq(hank_ctx *ctx, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
+    ENTER(ctx);
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "no primal sweep has been run");
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(out, ctx->R.pol, sizeof(double) * (size_t)ctx->c.P * ctx->c.G, hipMemcpyDeviceToHost, ctx->stream));
@@ -1285,6 +1348,7 @@ int hank_get_policy_seq(hank_ctx *ctx, double *out) {
 
 int hank_get_dist_seq(hank_ctx *ctx, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
+    ENTER(ctx);
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "no primal sweep has been run");
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(out, ctx->R.Dseq + ctx->c.G, sizeof(double) * (size_t)ctx->c.P * ctx->c.G, hipMemcpyDeviceToHost, ctx->stream));
@@ -1294,6 +1358,7 @@ int hank_get_dist_seq(hank_ctx *ctx, double *out) {
 
 int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
+    ENTER(ctx);
     const size_t total = (size_t)ctx->c.P * ctx->c.G * N;
     double *tmp = nullptr;
     if (ctx->last_tan == 1) {

@@ -18,12 +18,12 @@ _lib = None
 
 HANK_OK = 0
 HANK_ERR_NO_DEVICE, HANK_ERR_BAD_ARG, HANK_ERR_KNOTS, HANK_ERR_DOMAIN = 1, 2, 3, 4
-HANK_ERR_NOT_READY, HANK_ERR_NONMONOTONE, HANK_ERR_NOMEM, HANK_ERR_SWEEP = 5, 6, 7, 8
+HANK_ERR_NOT_READY, HANK_ERR_NONMONOTONE, HANK_ERR_NOMEM, HANK_ERR_SWEEP, HANK_ERR_LAUNCH = 5, 6, 7, 8, 9
 HANK_VF_KRUSELL_SMITH = 0
 
 # the symbols include/hank_hip.h declares (tests check that every one is exported)
 ABI_SYMBOLS = (
-    "hank_create", "hank_destroy", "hank_last_error", "hank_n_hh", "hank_set_stream", "hank_sync",
+    "hank_create", "hank_create_on", "hank_destroy", "hank_last_error", "hank_n_hh", "hank_set_stream", "hank_sync",
     "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
     "hank_primal_jvp", "hank_primal_jvp_dev",
     "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
     lib = C.CDLL(str(_LIB_PATH))
     dp, vp, i32 = C.POINTER(C.c_double), C.c_void_p, C.c_int32
     lib.hank_create.argtypes = [C.POINTER(hank_model), C.POINTER(vp)]
+    lib.hank_create_on.argtypes = [C.POINTER(hank_model), i32, C.POINTER(vp)]
     lib.hank_destroy.argtypes = [vp]
     lib.hank_last_error.argtypes = [vp]
     lib.hank_last_error.restype = C.c_char_p
@@ -139,8 +140,10 @@ class HouseholdBlock:
     All matrices are (n_a, n_e); numpy arrays of that shape are accepted in any memory order.
     """
 
-    def __init__(self, a_grid, z_grid, Pi, beta, gamma, borrow_cons, T, value_fn_id=HANK_VF_KRUSELL_SMITH):
+    def __init__(self, a_grid, z_grid, Pi, beta, gamma, borrow_cons, T, value_fn_id=HANK_VF_KRUSELL_SMITH, device=None):
+        """device: HIP device ordinal of the context (hank_create_on); None = the calling thread's current device."""
         self._lib = load_library()
+        self.device = device
         self._ctx = C.c_void_p()
         self.a_grid = np.ascontiguousarray(a_grid, dtype=np.float64)
         self.z_grid = np.ascontiguousarray(z_grid, dtype=np.float64)
@@ -151,7 +154,10 @@ class HouseholdBlock:
         self._boundary = None
         m = hank_model(self.n_a, self.n_e, self.T, value_fn_id, _p(self.a_grid), _p(self.z_grid),
                        _p(self.Pi), float(beta), float(gamma), float(borrow_cons))
-        rc = self._lib.hank_create(C.byref(m), C.byref(self._ctx))
+        if device is None:
+            rc = self._lib.hank_create(C.byref(m), C.byref(self._ctx))
+        else:
+            rc = self._lib.hank_create_on(C.byref(m), int(device), C.byref(self._ctx))
         if rc != HANK_OK:
             msg = self._lib.hank_last_error(self._ctx).decode() if self._ctx else "hank_create failed"
             if not msg and rc == HANK_ERR_NO_DEVICE:
@@ -169,11 +175,12 @@ class HouseholdBlock:
         if rc != HANK_OK:
             raise _ERR_CLASSES.get(rc, HankHIPError)(rc, self._lib.hank_last_error(self._ctx).decode())
 
-    def clone(self) -> "HouseholdBlock":
+    def clone(self, device=None) -> "HouseholdBlock":
         """A second, independent context of the same model and boundary (its own device memory, graphs and
-        stream): independent tangent batches — Jacobian column chunks — can be in flight on both."""
+        stream): independent tangent batches — Jacobian column chunks — can be in flight on both. `device`: put the
+        clone on another GPU of the node (default: this context's)."""
         beta, gamma, bc, vf = self._params
-        other = HouseholdBlock(self.a_grid, self.z_grid, self.Pi, beta, gamma, bc, self.T, vf)
+        other = HouseholdBlock(self.a_grid, self.z_grid, self.Pi, beta, gamma, bc, self.T, vf, device=self.device if device is None else device)
         if self._boundary is not None:
             other.set_boundary(*self._boundary)
         return other

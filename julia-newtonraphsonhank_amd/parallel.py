@@ -77,3 +77,44 @@ def assemble_columns(jvp_block: Callable, n: int, chunk: int = 512, group=None, 
     out = out.cpu()
     rows = [out[r * kmax: r * kmax + (shard_bounds(n, W, r)[1] - shard_bounds(n, W, r)[0])] for r in range(W)]
     return torch.cat(rows, dim=0).t().contiguous().numpy()
+
+
+class DeviceGroup:
+    """ONE host process driving one context per GPU of the node — the multi-GPU form behind the C ABI (hank_create_on;
+    INTEGRATION.md section 6): the model, boundary and primal are replicated, GPU g takes the tangent columns
+    `shard_bounds(N, len(devices), g)`, and the results land in ONE host array — no collective, no second process.
+    Every context is driven from its own host thread (the library releases the GIL inside a call and a context makes
+    its device current for the call), so the sweeps of all GPUs overlap. `block` is the context of devices[0]."""
+
+    def __init__(self, block, devices):
+        self.devices = list(devices)
+        if not self.devices:
+            raise ValueError("DeviceGroup needs at least one device")
+        self.blocks = [block] + [block.clone(device=d) for d in self.devices[1:]]
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=len(self.blocks))
+
+    def _each(self, fn, args_per_block=None):
+        futs = [self._pool.submit(fn, b, *(args_per_block[k] if args_per_block else ())) for k, b in enumerate(self.blocks)]
+        return [f.result() for f in futs]
+
+    def set_boundary(self, value, D):
+        self._each(lambda b: b.set_boundary(value, D))
+
+    def primal(self, x):
+        """the Float64 sweep on every GPU (redundant and cheap); returns the aggregates of the first."""
+        return self._each(lambda b: b.primal(x))[0]
+
+    def jvp(self, y):
+        """y: (n_hh, P, N) -> (P, N): columns sharded over the GPUs, assembled on the host."""
+        import numpy as np
+        y = np.asarray(y, dtype=np.float64)
+        N, W = y.shape[2], len(self.blocks)
+        bounds = [shard_bounds(N, W, g) for g in range(W)]
+        parts = self._each(lambda b, lo, hi: b.jvp(y[:, :, lo:hi]) if hi > lo else np.empty((y.shape[1], 0)), bounds)
+        return np.concatenate(parts, axis=1)
+
+    def close(self):
+        for b in self.blocks[1:]:
+            b.close()
+        self._pool.shutdown(wait=True)

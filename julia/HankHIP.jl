@@ -34,7 +34,7 @@ end
 const _FAMILIES = Dict(:ValueFunction => (0, (:r, :w)),                # KrusellSmith.jl:43-83, :53-54
                        :HANKValueFunction => (1, (:r, :om, :Tr)))      # one-asset HANK (not in the reference)
 
-const _CTX = IdDict{Any,HankCtx}()     # one device context per SequenceModel
+const _CTX = Dict{Tuple{UInt,Int},HankCtx}()     # one device context per (SequenceModel, HIP device); device -1 = the current one
 
 function _check(ctx::Ptr{Cvoid}, rc::Cint)
     rc == 0 && return
@@ -42,8 +42,10 @@ function _check(ctx::Ptr{Cvoid}, rc::Cint)
     error(msg)      # the library's messages restate the reference's own exceptions (knots / DomainError)
 end
 
-function hank_context(model::SequenceModel)
-    get!(_CTX, model) do
+# `device`: HIP device ordinal (hank_create_on) — one context per GPU of a node lets ONE Julia process shard the columns of
+# a tangent batch over the GPUs (sharded_jvp_columns below); `nothing` = the calling thread's current device (hank_create)
+function hank_context(model::SequenceModel; device::Union{Nothing,Integer} = nothing)
+    get!(_CTX, (objectid(model), device === nothing ? -1 : Int(device))) do
         w = model.heterogeneity.wealth; p = model.heterogeneity.productivity
         a = collect(Float64, w.grid); z = collect(Float64, p.grid); Π = Matrix{Float64}(p.transition)
         haskey(_FAMILIES, nameof(model.value_fn)) || error("no native kernel family for $(model.value_fn)")
@@ -52,7 +54,9 @@ function hank_context(model::SequenceModel)
         GC.@preserve a z Π begin
             m = HankModelC(w.n, p.n, model.compspec.T, fam_id, pointer(a), pointer(z), pointer(Π),
                            model.params.β, model.params.γ, model.params.borrow_cons)
-            rc = ccall((:hank_create, LIBHANK), Cint, (Ref{HankModelC}, Ref{Ptr{Cvoid}}), m, ref)
+            rc = device === nothing ?
+                ccall((:hank_create, LIBHANK), Cint, (Ref{HankModelC}, Ref{Ptr{Cvoid}}), m, ref) :
+                ccall((:hank_create_on, LIBHANK), Cint, (Ref{HankModelC}, Int32, Ref{Ptr{Cvoid}}), m, Int32(device), ref)
         end
         _check(ref[], rc)
         ctx = HankCtx(ref[], model.compspec.T - 1, w.n * p.n, w.n, p.n, rows)
@@ -140,4 +144,32 @@ function ForwardIteration(seqs::DevicePolicySeqs{TF}, model::SequenceModel, ss_i
     agg, dagg = seqs.agg, seqs.dagg
     out = seqs.N == 0 ? agg : [_mkdual(TF, agg[t], ntuple(n -> dagg[t, n], seqs.N)) for t in 1:length(agg)]
     return NamedTuple{seqs.het_keys}((out,))
+end
+
+# ---- one process, several GPUs (GeneralStructures.jl:542-550: JVP is linear in `tangent`, so tangent columns shard) ----------
+# dagg = J_household(x) * dxhh, the (P, N) household-block part of N JVPs at once, columns split over `devices`. Every
+# context replays the (cheap) Float64 sweep; GPU g takes the contiguous column block g; each task blocks in its own
+# `hank_primal_jvp` while the other GPUs run; the blocks land in ONE host matrix — no collective. This is what replaces the
+# column loop of `getSteadyStateJacobian` (SteadyStateJacobian.jl:240-243) or a `ForwardDiff.jacobian` chunk loop.
+function sharded_jvp_columns(model::SequenceModel, ss_end, ss_initial, xhh::Matrix{Float64}, dxhh::Array{Float64,3}; devices = [0])
+    P, N, W = size(dxhh, 2), size(dxhh, 3), length(devices)
+    dagg = Matrix{Float64}(undef, P, N)
+    base, extra = divrem(N, W)
+    value = Matrix{Float64}(ss_end.value); D0 = Vector{Float64}(ss_initial.D)
+    @sync for (g, dev) in enumerate(devices)
+        lo = (g - 1) * base + min(g - 1, extra) + 1
+        hi = lo + base + (g <= extra ? 1 : 0) - 1
+        hi < lo && continue
+        Threads.@spawn begin                     # a context is used by ONE task at a time; different contexts run concurrently
+            ctx = hank_context(model; device = dev)
+            _check(ctx.ptr, ccall((:hank_set_boundary, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, value, D0))
+            agg = Vector{Float64}(undef, P)
+            blk = dxhh[:, :, lo:hi]
+            out = Matrix{Float64}(undef, P, hi - lo + 1)
+            _check(ctx.ptr, ccall((:hank_primal_jvp, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}),
+                                  ctx.ptr, xhh, blk, Int32(hi - lo + 1), agg, out))
+            dagg[:, lo:hi] = out
+        end
+    end
+    return dagg
 end

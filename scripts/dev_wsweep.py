@@ -118,12 +118,18 @@ if __name__ == "__main__":
         parity(37, 3, 9, 70, envs=(SL,))
         parity(500, 4, 300, 40, shock=0.01, envs=(SL,))
         parity(2000, 11, 300, 32, shock=0.01, envs=(SL,))
+        parity(2000, 11, 300, 128, shock=0.01, envs=(SL, dict(SL, HANK_W_DW=2, HANK_W_NW=7), dict(SL, HANK_W_DW=4, HANK_W_NW=3), dict(SL, HANK_W_ALLROWS=1)))
     if what in ("all", "time"):
         Ns = [int(v) for v in sys.argv[2:]] or [1, 8, 16, 32, 64, 128, 256]
         timing(2000, 11, 300, Ns, envs=(SL, COL, {"SCHED": "launch"}))
+    if what == "col":
+        timing(2000, 11, 300, [int(v) for v in sys.argv[2:]] or [32], envs=(COL,), reps=5)
     if what == "slab":
         timing(2000, 11, 300, [int(v) for v in sys.argv[2:]] or [256], envs=(SL,), reps=3)
-    if what == "tune32":
-        timing(2000, 11, 300, [32], envs=({"HANK_W_DW": 4, "HANK_W_NW": 1}, {"HANK_W_DW": 2, "HANK_W_NW": 2}, {"HANK_W_DW": 1, "HANK_W_NW": 4}))
-        timing(2000, 11, 300, [64], envs=({"HANK_W_DW": 4, "HANK_W_NW": 2}, {"HANK_W_DW": 2, "HANK_W_NW": 4}, {"HANK_W_DW": 1, "HANK_W_NW": 8}))
-        timing(2000, 11, 300, [256], envs=({"HANK_W_DW": 4, "HANK_W_NW": 8}, {"HANK_W_DW": 4, "HANK_W_NW": 4}, {"HANK_W_DW": 2, "HANK_W_NW": 8}))
+    if what == "tune":
+        def E(dw, nw, **kw):
+            return dict(SL, HANK_W_DW=dw, HANK_W_NW=nw, **kw)
+        timing(2000, 11, 300, [32], envs=(E(4, 1), E(2, 2), E(1, 4), E(2, 2, HANK_W_ALLROWS=1)))
+        timing(2000, 11, 300, [128], envs=(E(4, 4), E(4, 3), E(2, 7), E(2, 4), E(4, 4, HANK_W_ALLROWS=1)))
+        timing(2000, 11, 300, [256], envs=(E(4, 4), E(4, 3), E(2, 7)))
+        timing(2000, 11, 300, [1, 8, 16, 64], envs=(SL,))
