@@ -107,6 +107,16 @@ def cpu_baseline(m, ss, x, Z, budget_s=12.0):
                           "sample": f"{nall} single-tangent JVPs, one per thread at a time, in {elall:.1f} s on {cores} threads"}}
 
 
+def kernel_source_sha16():
+    """hash of the device sources the library is built from: profiles/pmc_latest.json records the one its counters were
+    collected on (scripts/update_pmc_latest.py), `roofline.traffic_stale` says when they no longer match."""
+    import hashlib
+    h_ = hashlib.sha256()
+    for f in sorted((ROOT / "julia-newtonraphsonhank_amd" / "csrc").glob("*.h*")):
+        h_.update(f.read_bytes())
+    return h_.hexdigest()[:16]
+
+
 def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     """second half of the BASELINE metric ("wall-clock to converged path, Krusell-Smith T=300") on
     configs[1] (500x4), and the JVP rate of a wider tangent batch on the headline grid."""
@@ -159,9 +169,17 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     else:
         kb, kf, np_ = "dual_backward", "dual_forward", 1
         per = tm["dual_backward"]["launches"] * (1 + Nw)
+    b_alg_w = 2 * P * G8 * (1 + Nw)
+    slow = kb if tm[kb]["ms"] >= tm[kf]["ms"] else kf
+    ach_w = G8 * per / (1e-3 * tm[slow]["ms"]) / 1e9
     extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el, "passes": np_,
                            "backward_sweep_GBs": G8 * per / (1e-3 * tm[kb]["ms"]) / 1e9,
-                           "forward_sweep_GBs": G8 * per / (1e-3 * tm[kf]["ms"]) / 1e9}
+                           "forward_sweep_GBs": G8 * per / (1e-3 * tm[kf]["ms"]) / 1e9,
+                           # the same object as the headline's, for the slower sweep of the wide batch (HIP events on the library's stream)
+                           "roofline": {"bound": "hbm", "kernel": ("k_xtan_" if hb.stats()["schedule"] == 1 else "k_fused_") + ("back" if slow == kb else "fwd"),
+                                        "achieved": ach_w, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_w / HBM_PEAK_GBS, "traffic": None,
+                                        "sweep_ms": tm[slow]["ms"], "launches": tm[slow]["launches"]},
+                           "whole_batch": {"B_alg_bytes": b_alg_w, "achieved_GBs": b_alg_w / el / 1e9, "frac_of_hbm_peak": b_alg_w / el / 1e9 / HBM_PEAK_GBS}}
     # the y-iteration's access pattern (NewtonRaphson.jl:91-111): ONE primal, then JVP batches at that record
     hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
     Nj = N
@@ -183,11 +201,12 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     hb.sync()
     extra["single_tangent_jvp_ms"] = 1e3 * (time.perf_counter() - t0) / reps
     # configs[1]'s grid with a mild shock and with RunMain.jl's Z_t = 1 + 0.8^t, then the headline grid
-    for n_a, n_e, shock in ((500, 4, 0.01), (500, 4, 0.8), (2000, 11, 0.01)):
+    # (the last two: the headline grid with the reference's damped fixed point, then with the opt-in Krylov inner loop)
+    for n_a, n_e, shock, inner in ((500, 4, 0.01, "fixed_point"), (500, 4, 0.8, "fixed_point"), (2000, 11, 0.01, "fixed_point"), (2000, 11, 0.01, "krylov")):
         try:
-            res, _ = solve(n_a, n_e, 300, shock)
+            res, _ = solve(n_a, n_e, 300, shock, inner=inner)
         except Exception as e:          # noqa: BLE001 - report, do not kill the bench line
-            res = {"grid": f"{n_a}x{n_e}", "T": 300, "shock": shock, "error": str(e)[:200]}
+            res = {"grid": f"{n_a}x{n_e}", "T": 300, "shock": shock, "inner": inner, "error": str(e)[:200]}
         extra["converged_path"].append(res)
     # the whole RunMain sequence at the headline grid with NOTHING cached: steady state from the YAML guesses (value iteration
     # and stationary distribution as persistent launches on the device), then J̅ and Newton
@@ -326,14 +345,17 @@ def main():
         achieved = bytes_per_launch / avg_launch_s / 1e9
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs, profiles/r01b_pmc_*): a profile artefact, not measured live
-        pmc, traffic = None, None
+        pmc, traffic, traffic_stale = None, None, None
         pmc_file = ROOT / "profiles" / "pmc_latest.json"
         if pmc_file.exists() and N == WORKLOADS[args.workload]["N"]:
             try:
-                pmc = json.loads(pmc_file.read_text()).get(args.workload, {}).get(kname)
+                rec = json.loads(pmc_file.read_text()).get(args.workload, {})
+                pmc = rec.get(kname)
                 traffic = pmc["hbm_bytes"] if pmc else None
+                # the counters belong to the kernel sources they were collected on: a different hash = re-profile
+                traffic_stale = (rec.get("kernel_source_sha16") != kernel_source_sha16()) if pmc else None
             except Exception:
-                pmc, traffic = None, None
+                pmc, traffic, traffic_stale = None, None, None
         b_alg_batch = 2 * P * G * 8 * (1 + N)
         out = {
             "metric": "sequence-space JVPs/sec (household block: BackwardIteration+ForwardIteration+aggregation, Krusell-Smith T=300)",
@@ -345,7 +367,7 @@ def main():
                                 "1 dual-sweep pass: primal + N tangents (hank_primal_jvp)") + (" + RCCL all-gather" if use_dist else ""),
                        "parallelism": f"tangent-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": pmc,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale, "traffic_detail": pmc,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_launch_s,
                          "schedule": "xcd-persistent" if schedule == 1 else "launch-per-period",
                          "note": "avg launch = HIP-event time of the sweep's kernels on the library's stream / launches"},

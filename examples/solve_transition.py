@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The RunMain.jl sequence (RunMain.jl:35-55, as intended — SURVEY.md §3.1) on the MI355X build:
 
-    YAML -> model -> steady state (host) -> J̅ (batched unit-tangent JVPs on the GPU)
+    YAML -> model -> steady state (host) -> J̅ (its Toeplitz structure from n_hh backward tangent sweeps on the GPU; or n unit tangents)
          -> NewtonRaphsonHANK (Boehl y-iteration; one hank_jvp per inner iteration) -> converged path
 
     python examples/solve_transition.py [--n-a 500 --n-e 4 --T 300 --shock 0.01]
@@ -21,7 +21,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False, cold=False):
+def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False, cold=False, inner="fixed_point", jacobian="toeplitz"):
     """cold=True: the steady state is solved here from the YAML guesses (value iteration and stationary distribution on
     the device where one is present) instead of coming from the test fixtures' cache."""
     import hank_amd as h
@@ -39,17 +39,18 @@ def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False, cold=False
     Z = 1.0 + shock * 0.8 ** np.arange(1, P + 1)                       # RunMain.jl:22-23
     x0 = np.tile(np.array([ss.vars[k] for k in ("Y", "KS", "r", "w")]), P)   # SteadyState.jl:277-278
     t0 = time.perf_counter()
-    J = h.getSteadyStateJacobian(ss, m)
+    J = h.getSteadyStateJacobian(ss, m, method=jacobian)
     t_jac = time.perf_counter() - t0
     h.y_Iteration.total_jvps = 0
     t0 = time.perf_counter()
-    x = h.NewtonRaphsonHANK(x0, J, {"Z": Z}, m, ss, ss, ε=eps, verbose=verbose)
+    x = h.NewtonRaphsonHANK(x0, J, {"Z": Z}, m, ss, ss, ε=eps, verbose=verbose, inner=inner)
     t_newton = time.perf_counter() - t0
     lin = h.LinearizedFunction(x, {"Z": Z}, m, ss, ss)
     return {"grid": f"{n_a}x{n_e}", "T": T, "shock": f"Z_t = 1 + {shock}*0.8^t", "steady_state_s": round(t_ss, 3),
             "ss_jacobian_s": round(t_jac, 3), "newton_s": round(t_newton, 3),
             "newton_iterations": h.NewtonRaphsonHANK.iterations, "jvps": h.y_Iteration.total_jvps, "residual_norm": float(np.linalg.norm(lin.Fx)),
-            "wall_to_converged_path_s": round(t_jac + t_newton, 3), "steady_state": "cold start" if cold else "cached"}, x
+            "wall_to_converged_path_s": round(t_jac + t_newton, 3), "steady_state": "cold start" if cold else "cached",
+            "inner": inner, "jacobian": jacobian}, x
 
 
 def solve_permanent(n_a=200, n_e=3, T=150, Z_end=1.03, eps=1e-9, verbose=False):
@@ -88,6 +89,8 @@ if __name__ == "__main__":
     ap.add_argument("--permanent", type=float, default=None, metavar="Z_END", help="two-steady-state scenario: Z jumps to Z_END for good")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--cold", action="store_true", help="solve the steady state from the YAML guesses (no fixture)")
+    ap.add_argument("--inner", default="fixed_point", choices=["fixed_point", "krylov"], help="y-iteration: the reference's damped fixed point or GMRES on J(x) preconditioned by the steady-state Jacobian")
+    ap.add_argument("--jacobian", default="toeplitz", choices=["toeplitz", "columns"])
     a = ap.parse_args()
     import os
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -100,7 +103,7 @@ if __name__ == "__main__":
     if a.permanent is not None:
         out = solve_permanent(a.n_a, a.n_e, a.T, a.permanent, verbose=a.verbose)[0]
     else:
-        out, x = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose, cold=a.cold)
+        out, x = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose, cold=a.cold, inner=a.inner, jacobian=a.jacobian)
     out["n_gpus"] = world
     if rank == 0:
         print(json.dumps(out))

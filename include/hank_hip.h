@@ -178,6 +178,20 @@ int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t max_iter, d
 int hank_stationary_dist(hank_ctx *ctx, const double *policy, double *D_io, double tol, int32_t max_iter, int32_t check_every,
                          int32_t *iters_out);
 
+/* hank_fake_news: the household block's sequence-space Jacobian AT THE STEADY STATE from its Toeplitz structure — what
+ * getSteadyStateJacobian assembles from n_endog backward JVPs seeded at the last period (JBI, SteadyStateJacobian.jl:240-243),
+ * the pullbacks through ForwardIteration (JFI, :249-253), `helper[t,s] = JFI[:, t-slice] * JBI[s-slice, :]` (:300-305) and
+ * the recursion J̅[s,t] = J̅[s-1,t-1] + helper (:363-371). Here: ONE backward tangent sweep of n_hh directions (unit shock to
+ * household input k in the last period: the policy response at every lag), one single-period forward push of all P*n_hh lagged
+ * responses (the lottery impulse), P-1 steps of the transposed forward step (the expectation vectors), one product.
+ * Requires hank_primal at the constant steady-state path with the steady state as both boundaries.
+ *   F_out  (P, P, n_hh) column-major: F[u, j, k] = effect on the aggregate, u periods after the policy moved, of the policy
+ *          response with j periods to go before a unit shock to input k (the reference's helper; "fake news" matrix)
+ *   Dv_out (P, n_hh): Dv[j, k] = the direct term, (policy response at lag j) . D_ss
+ * d agg_t / d xhh_{k,s} = J_k[t, s] with J_k[t, s] = J_k[t-1, s-1] + F[t, s, k], J_k[0, s] = Dv[s, k] + F[0, s, k],
+ * J_k[t, 0] = F[t, 0, k] for t > 0 (0-based; hank_amd.SteadyStateJacobian.household_jacobian does the recursion). */
+int hank_fake_news(hank_ctx *ctx, double *F_out, double *Dv_out);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------
  * Device time, in milliseconds, of the sweeps of the most recent hank_primal[_dev]/hank_jvp[_dev],
  * from HIP events recorded on the context's stream around each sweep:

@@ -119,10 +119,14 @@ def _lu_solver(J):
 
 @host_algebra
 def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, precond=None,
-                α: float = 1.0, γ: float = 1.5, ε: float = 1e-9, verbose: bool = False, max_inner: int = 10_000,
-                linear_solver: str = "lu"):
-    """inner fixed-point iteration for the search direction (NewtonRaphson.jl:65-114):
-    y ← y + α·J̅⁻¹(F(x) − J(x)·y), α = 0.5 hard-coded as in the reference (:102)."""
+                α: float | None = None, γ: float = 1.5, ε: float = 1e-9, verbose: bool = False, max_inner: int = 10_000,
+                linear_solver: str = "lu", inner: str = "fixed_point"):
+    """inner iteration for the search direction y with J(x)·y = F(x) (NewtonRaphson.jl:65-114).
+
+    inner="fixed_point" (default, the reference): y ← y + α·J̅⁻¹(F(x) − J(x)·y). The reference accepts α (:72) and
+    overrides it with 0.5 (:102): `α=None` is that; a value passed here is honoured (α = 1 is the undamped iteration).
+    inner="krylov" (opt-in, not in the reference): GMRES on J(x) with J̅⁻¹ as right preconditioner — the same fixed point
+    (the exact Newton step) in a handful of JVPs instead of the ≈ 21 that α = 0.5 needs to contract 1e-9 by halves."""
     lin = LinearizedFunction(x, exog_paths, mod, ss_initial, ss_ending)
     y = np.asarray(y0, dtype=np.float64)
     n = len(y)
@@ -130,6 +134,28 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
     Fx = lin.Fx
     i = 1
     solve = _lu_solver(J̅) if linear_solver == "lu" else None
+    if inner == "krylov":
+        count = [0]
+
+        def matvec(v):
+            count[0] += 1
+            return lin.jvp(np.asarray(v, dtype=np.float64).ravel())
+
+        Pinv = spla.LinearOperator((n, n), matvec=(solve if solve is not None else (lambda b: _gmres(J̅, b, np.zeros(n)))), dtype=np.float64)
+        A = spla.LinearOperator((n, n), matvec=matvec, dtype=np.float64)
+        # right-preconditioned: J(x) J̅⁻¹ z = F(x), y = J̅⁻¹ z; J(x) J̅⁻¹ ≈ I near the steady state. Stop when the linear residual is
+        # below ε relative to ‖F(x)‖ and below 1e-3 ε absolutely (the outer loop's ‖y‖ ≤ ε test then sees a converged step)
+        AP = spla.LinearOperator((n, n), matvec=lambda z: matvec(Pinv.matvec(z)), dtype=np.float64)
+        z, info = spla.gmres(AP, Fx, rtol=min(1e-10, ε), atol=1e-3 * ε, restart=min(30, n), maxiter=max(1, max_inner // 30))
+        y = Pinv.matvec(z)
+        y_Iteration.last_jvp_count = count[0]
+        y_Iteration.total_jvps = getattr(y_Iteration, "total_jvps", 0) + count[0]
+        if verbose:
+            print(f"y_Iteration (krylov): {count[0]} JVPs, info={info}, ‖F − J y‖={np.linalg.norm(Fx - lin.jvp(y))}")
+        return y
+    if inner != "fixed_point":
+        raise ValueError(f"unknown inner iteration {inner!r} (fixed_point | krylov)")
+    step = 0.5 if α is None else float(α)
     while ε < np.linalg.norm(y - y_old) and i < max_inner:
         Λxy = lin.jvp(y)
         if solve is not None:
@@ -140,12 +166,11 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
             M = _gmres(J̅, Λxy, M)
         with np.errstate(divide="ignore", invalid="ignore"):      # printed only (:101, :108-110); NaN at y = 0 like Julia
             ray = np.divide(y @ M, y @ y) if verbose else np.nan
-        α = 0.5
         y_old = y
-        y = y_old + α * R
+        y = y_old + step * R
         i += 1
         if verbose and i % 10 == 0:
-            print(f"y_Iteration {i}: α={α}  ‖y−y_old‖={np.linalg.norm(y - y_old)}  ray={ray}")
+            print(f"y_Iteration {i}: α={step}  ‖y−y_old‖={np.linalg.norm(y - y_old)}  ray={ray}")
     y_Iteration.last_jvp_count = i - 1
     y_Iteration.total_jvps = getattr(y_Iteration, "total_jvps", 0) + i - 1
     return y
@@ -153,13 +178,14 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
 
 @host_algebra
 def NewtonRaphsonHANK(x_0, J̅, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, ε: float = 1e-9,
-                      verbose: bool = False, linear_solver: str = "lu"):
-    """outer Newton loop (NewtonRaphson.jl:27-46): x ← x − y until ‖y‖ ≤ ε or 100 iterations."""
+                      verbose: bool = False, linear_solver: str = "lu", inner: str = "fixed_point", α: float | None = None):
+    """outer Newton loop (NewtonRaphson.jl:27-46): x ← x − y until ‖y‖ ≤ ε or 100 iterations. `inner` / `α`: see y_Iteration
+    (defaults = the reference's damped fixed point)."""
     x = np.asarray(x_0, dtype=np.float64)
     y = x.copy()
     i = 1
     while ε < np.linalg.norm(y) and i < 100:
-        y = y_Iteration(J̅, x, y, exog_paths, mod, ss_initial, ss_ending, verbose=verbose, linear_solver=linear_solver)
+        y = y_Iteration(J̅, x, y, exog_paths, mod, ss_initial, ss_ending, verbose=verbose, linear_solver=linear_solver, inner=inner, α=α)
         x = x - y
         i += 1
         if verbose:

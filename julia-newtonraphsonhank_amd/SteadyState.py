@@ -43,6 +43,16 @@ class SSAssembler:
             raise ValueError(f"vfi must be 'auto', 'device' or 'host' (got {vfi!r})")
         from .hip import device_available
         self.vfi_on_device = vfi == "device" or (vfi == "auto" and device_available())
+        if vfi == "auto" and self.vfi_on_device:
+            # a model the device block cannot take (more than one exogenous dimension, a grid it refuses) keeps the host
+            # loop, which handles it through the kron of the transitions. Errors of the device sweeps themselves
+            # (KnotsNotSorted / DomainError at a price iterate) surface from F(p) as they do on the host.
+            from .BackwardIteration import household_block
+            from .hip import HankHIPError
+            try:
+                household_block(model)
+            except (ValueError, HankHIPError):
+                self.vfi_on_device = False
         self.vfi_steps = 0
         self.all_keys = var_names(model)
         self.free_keys = tuple(k for k in vars_of_type(model, "endogenous") if k not in ss_spec.fixed)

@@ -13,10 +13,16 @@ import functools
 import os
 
 
+_CONTROLLER = None
+
+
 def host_threads():
-    """context manager capping the BLAS / OpenMP thread pools for the enclosed host algebra."""
+    """context manager CAPPING the BLAS / OpenMP thread pools at HANK_HOST_THREADS for the enclosed host algebra: a pool that
+    is already smaller (OMP_NUM_THREADS=1 under torchrun, say) is left as it is — `threadpool_limits(limits=n)` alone would
+    raise it to n. The library scan is done once per process (ThreadpoolController)."""
+    global _CONTROLLER
     try:
-        from threadpoolctl import threadpool_limits
+        from threadpoolctl import ThreadpoolController
     except ImportError:                      # optional dependency: run with the pools as they are
         return contextlib.nullcontext()
     try:
@@ -25,7 +31,13 @@ def host_threads():
         n = 8
     if n <= 0:
         return contextlib.nullcontext()
-    return threadpool_limits(limits=n)
+    if _CONTROLLER is None:
+        _CONTROLLER = ThreadpoolController()
+    over = [lib for lib in _CONTROLLER.lib_controllers if (lib.num_threads or 0) > n]
+    if not over:
+        return contextlib.nullcontext()
+    limits = {lib.prefix: n for lib in over if lib.prefix}
+    return _CONTROLLER.limit(limits=limits) if limits else contextlib.nullcontext()
 
 
 def host_algebra(fn):

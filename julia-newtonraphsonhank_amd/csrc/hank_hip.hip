@@ -6,6 +6,7 @@
 #include "hank_kernels.h"
 #include "hank_xsweep.h"
 #include "hank_wsweep.h"
+#include "hank_jacobian.h"
 #include "../../include/hank_hip.h"
 
 #include <cstdarg>
@@ -83,6 +84,9 @@ struct XWork {
     int *rdrB = nullptr, *rdrF = nullptr;     // [P][Sact] the inverse: which members read a member's rows
     int2 *pubB = nullptr;                     // [P][Sact][16] backward slab sweep: which rows a member stores to L2 (k_wpub_back)
     int lds_max = 65536;
+    int fault_where = 7;
+    int fault = 0;                            // dev knob HANK_XFAULT=placement: every persistent launch finds its status word set ("a
+                                              // group is short of members") and leaves at once — exercises the fallback paths
     bool src_valid = false;
     std::list<XTan> tans;           // most recently used first
     int last_passes = 0;            // sync blocks the last call used (their status words are checked)
@@ -118,6 +122,7 @@ struct hank_ctx {
     int last_tan = 0;              // which implementation ran the last tangent sweep (0 launches, 1 persistent): hank_get_dpolicy_seq
     int xjvp_max = 64;             // auto: batches up to this width take the persistent tangent sweeps (measured crossover)
     XWork xw;
+    struct { double *dpT = nullptr, *iota = nullptr, *E = nullptr, *Cp = nullptr, *F = nullptr, *Dv = nullptr; int N = 0; } fn;   // hank_fake_news workspace
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // see hank_stats
     hipEvent_t ev_stream = nullptr;
@@ -509,6 +514,11 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.rdrF, P * X.Sact));
     HIPC(ctx, dmalloc(&X.pubB, P * X.Sact * 16));
     X.lds_max = (int)prop.sharedMemPerBlock;
+    if (const char *xf = getenv("HANK_XFAULT")) {      // "placement" | "timeout", optionally ":primal" | ":tangent" | ":fixedpoint" (default: every persistent launch)
+        X.fault = strncmp(xf, "placement", 9) == 0 ? XERR_PLACEMENT : (strncmp(xf, "timeout", 7) == 0 ? XERR_TIMEOUT : 0);
+        const char *w = strchr(xf, ':');
+        X.fault_where = !w ? 7 : (strcmp(w, ":primal") == 0 ? 1 : (strcmp(w, ":tangent") == 0 ? 2 : (strcmp(w, ":fixedpoint") == 0 ? 4 : 7)));
+    }
     HIPC(ctx, hipMemset(X.Dvirt, 0, sizeof(double) * P * c.n_e * 64));
     X.ready = true;
     return HANK_OK;
@@ -652,6 +662,19 @@ static void w_launch_nec(int NEC, bool back, dim3 grd, dim3 blk, size_t lds, hip
     else WL(16);
 #undef WL
 }
+// version 3 of the backward slab sweep (rolled columns, no loader wave)
+template <int DW>
+static void v_launch_nec(int NEC, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const WTanBackArgs &ab) {
+    if (NEC == 4) hipLaunchKernelGGL((k_vtan_back<DW, 4, 512>), grd, blk, lds, s, ab);
+    else if (NEC == 8) hipLaunchKernelGGL((k_vtan_back<DW, 8, 512>), grd, blk, lds, s, ab);
+    else if (NEC == 12) hipLaunchKernelGGL((k_vtan_back<DW, 12, 512>), grd, blk, lds, s, ab);
+    else hipLaunchKernelGGL((k_vtan_back<DW, 16, 512>), grd, blk, lds, s, ab);
+}
+static void v_launch_back(int DW, int NEC, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const WTanBackArgs &ab) {
+    if (DW == 1) v_launch_nec<1>(NEC, grd, blk, lds, s, ab);
+    else if (DW == 2) v_launch_nec<2>(NEC, grd, blk, lds, s, ab);
+    else v_launch_nec<4>(NEC, grd, blk, lds, s, ab);
+}
 static void w_launch(int DW, int NEC, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const WTanBackArgs &ab, const WTanFwdArgs &af) {
     if (DW == 1) w_launch_nec<1>(NEC, back, grd, blk, lds, s, ab, af);
     else if (DW == 2) w_launch_nec<2>(NEC, back, grd, blk, lds, s, ab, af);
@@ -671,6 +694,13 @@ static int x_serialize_end(hank_ctx *ctx) {
     return HANK_OK;
 }
 
+// zero the sync blocks of the launches about to be enqueued (and, under the dev knob, pre-set their status words)
+static int x_sync_reset(hank_ctx *ctx, XSync *base, int count, int where) {     // where: 1 primal sweeps, 2 tangent sweeps, 4 the steady state's fixed points
+    HIPC(ctx, hipMemsetAsync(base, 0, sizeof(XSync) * (size_t)count, ctx->stream));
+    if (ctx->xw.fault && (ctx->xw.fault_where & where)) hipLaunchKernelGGL(k_xpoison, dim3(1), dim3(64), 0, ctx->stream, base, count, (unsigned)ctx->xw.fault);
+    return HANK_OK;
+}
+
 // the Float64 recurrences at the context's current x (d_xhh) and boundary: two persistent launches on ONE XCD's
 // workgroups (the policy sequence, the distribution path and the linearisation record the tangent sweeps read)
 static int x_run_primal(hank_ctx *ctx) {
@@ -680,7 +710,8 @@ static int x_run_primal(hank_ctx *ctx) {
     hipStream_t s = ctx->stream;
     int rc = x_serialize_begin(ctx);
     if (rc) return rc;
-    HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync) * 2, s));
+    rc = x_sync_reset(ctx, X.sync, 2, 1);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
     // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
@@ -729,7 +760,8 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     if (rc) return rc;
     const int np = (int)w->passes.size(), N = w->N;
     // sync blocks 0, 1 belong to the primal sweeps (their status is checked with this call's when both ran unchecked)
-    HIPC(ctx, hipMemsetAsync(X.sync + 2, 0, sizeof(XSync) * 2 * np, s));
+    rc = x_sync_reset(ctx, X.sync + 2, 2 * np, 2);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);     // (the primal may have been recorded by the launches)
     if (!X.src_valid) {      // once per recorded primal: which members each member's gathers read, period by period
@@ -759,7 +791,9 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
         for (int p = 0; p < np; p++) {
             const XPass &ps = w->passes[p];
             ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.NW = ps.NW; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
-            w_launch(ps.D, NEC, true, grd, dim3(64 * (ps.NW + 1)), wback_lds(c.n_e, NEC, ps.D, ps.NW), s, ab, af);
+            const char *v3 = getenv("HANK_W_V3");
+            if (v3 && atoi(v3) != 0) v_launch_back(ps.D, NEC, grd, dim3(64 * ps.NW), vback_lds(c.n_e, NEC, ps.D, ps.NW), s, ab);
+            else w_launch(ps.D, NEC, true, grd, dim3(64 * (ps.NW + 1)), wback_lds(c.n_e, NEC, ps.D, ps.NW), s, ab, af);
         }
         HIPC(ctx, hipEventRecord(ctx->ev[4], s));
         HIPC(ctx, hipEventRecord(ctx->ev[7], s));
@@ -967,6 +1001,7 @@ int hank_destroy(hank_ctx *ctx) {
     ctx->tws.clear();
     ctx->tw = nullptr;
     x_free(ctx);
+    (void)hipFree(ctx->fn.dpT); (void)hipFree(ctx->fn.iota); (void)hipFree(ctx->fn.E); (void)hipFree(ctx->fn.Cp); (void)hipFree(ctx->fn.F); (void)hipFree(ctx->fn.Dv);
     if (ctx->ev_stream) (void)hipEventDestroy(ctx->ev_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_side) (void)hipEventDestroy(ctx->ev_side);
@@ -1301,6 +1336,73 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
     return HANK_OK;
 }
 
+// The household block's sequence-space Jacobian at a stationary primal from its Toeplitz structure (hank_jacobian.h):
+// F (P, P, n_hh) and Dv (P, n_hh), column-major. Requires hank_primal at the constant steady-state path with the steady
+// state as both boundaries (what getSteadyStateJacobian builds, SteadyStateJacobian.jl:53-57).
+int hank_fake_news(hank_ctx *ctx, double *F_out, double *Dv_out) {
+    ENTER(ctx);
+    if (!ctx || !F_out || !Dv_out) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
+    if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_fake_news");
+    const Consts &c = ctx->c;
+    const int P = c.P, G = c.G, N = c.n_hh, NP = P * N, S = 16;
+    hipStream_t s = ctx->stream;
+    // 1. n_hh backward tangent sweeps (one batch) seeded at the last period: every lag of the policy response
+    int rc = ensure_tanwork(ctx, N);
+    if (rc) return rc;
+    TanWork &w = *ctx->tw;
+    rc = ensure_graphs(ctx, w, 0);
+    if (rc) return rc;
+    if (!ctx->fn.dpT) {
+        auto alloc = [&]() -> int {
+            HIPC(ctx, dmalloc(&ctx->fn.dpT, (size_t)G * NP)); HIPC(ctx, dmalloc(&ctx->fn.iota, (size_t)G * NP));
+            HIPC(ctx, dmalloc(&ctx->fn.E, (size_t)P * G)); HIPC(ctx, dmalloc(&ctx->fn.Cp, (size_t)S * P * NP));
+            HIPC(ctx, dmalloc(&ctx->fn.F, (size_t)P * NP)); HIPC(ctx, dmalloc(&ctx->fn.Dv, (size_t)NP));
+            return HANK_OK;
+        };
+        rc = alloc();
+        if (rc) {
+            (void)hipFree(ctx->fn.dpT); (void)hipFree(ctx->fn.iota); (void)hipFree(ctx->fn.E); (void)hipFree(ctx->fn.Cp); (void)hipFree(ctx->fn.F); (void)hipFree(ctx->fn.Dv);
+            ctx->fn = {};
+            (void)hipGetLastError();
+            return rc;
+        }
+    }
+    HIPC(ctx, join_side(ctx));      // D_1 and the {w, ig D} records come from the primal's forward sweep
+    hipLaunchKernelGGL(k_fn_seed, dim3((unsigned)((N * P * N + 255) / 256)), dim3(256), 0, s, w.dxhh, N, P);
+    HIPC(ctx, hipGraphLaunch(w.g_back, s));
+    for (TanWork &t : ctx->tws) t.valid = false;      // (w.dpol no longer belongs to a caller's batch)
+    for (XTan &t : ctx->xw.tans) t.valid = false;
+    // 2. the lottery impulse of every lag and input at once
+    hipLaunchKernelGGL(k_fn_transpose, dim3((unsigned)((G + 31) / 32), (unsigned)((P + 31) / 32), (unsigned)N), dim3(256), 0, s, w.dpol, P, G, N, ctx->fn.dpT);
+    hipLaunchKernelGGL(k_fn_impulse, dim3((unsigned)c.n_a, (unsigned)((NP + 255) / 256)), dim3(256), 0, s, c, ctx->R, ctx->fn.dpT, NP, ctx->fn.iota);
+    // 3. the expectation vectors E_u = (T')^u pol_ss
+    HIPC(ctx, hipMemcpyAsync(ctx->fn.E, ctx->R.pol, sizeof(double) * G, hipMemcpyDeviceToDevice, s));
+    for (int u = 0; u + 1 < P; u++)
+        hipLaunchKernelGGL(k_fn_expect, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, s, c, ctx->R, ctx->fn.E + (size_t)u * G, ctx->fn.E + (size_t)(u + 1) * G);
+    // 4. F = E iota, Dv = D_ss' dpT
+    const int kchunk = ((G + S - 1) / S + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_fn_gemm, dim3((unsigned)((NP + 63) / 64), (unsigned)((P + 63) / 64), (unsigned)S), dim3(256), 0, s, ctx->fn.E, ctx->fn.iota, ctx->fn.Cp, P, NP, G, kchunk);
+    hipLaunchKernelGGL(k_fn_reduce, dim3((unsigned)((P * NP + 255) / 256)), dim3(256), 0, s, ctx->fn.Cp, P * NP, S, ctx->fn.F);
+    hipLaunchKernelGGL(k_fn_gemm, dim3((unsigned)((NP + 63) / 64), 1, (unsigned)S), dim3(256), 0, s, ctx->R.Dseq + G, ctx->fn.dpT, ctx->fn.Cp, 1, NP, G, kchunk);
+    hipLaunchKernelGGL(k_fn_reduce, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, s, ctx->fn.Cp, NP, S, ctx->fn.Dv);
+    HIPC(ctx, hipGetLastError());
+    std::vector<double> hF((size_t)P * NP), hD((size_t)NP);
+    HIPC(ctx, hipMemcpyAsync(hF.data(), ctx->fn.F, sizeof(double) * hF.size(), hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipMemcpyAsync(hD.data(), ctx->fn.Dv, sizeof(double) * hD.size(), hipMemcpyDeviceToHost, s));
+    HIPC(ctx, hipStreamSynchronize(s));
+    rc = fetch_device_error(ctx);
+    if (rc) return rc;
+    // column n' = t*N + k of the device arrays is lag j = P-1-t of input k
+    for (int k = 0; k < N; k++)
+        for (int t = 0; t < P; t++) {
+            const int j = P - 1 - t;
+            Dv_out[j + (size_t)P * k] = hD[(size_t)t * N + k];
+            for (int u = 0; u < P; u++) F_out[u + (size_t)P * (j + (size_t)P * k)] = hF[(size_t)u * NP + (size_t)t * N + k];
+        }
+    ctx->errmsg[0] = 0;
+    return HANK_OK;
+}
+
 #ifdef HANK_XSTAMP
 // dev build: the stamps of the last sweeps (see hank_xsweep.h)
 int hank_debug_stamps(hank_ctx *ctx, unsigned long long *out) {
@@ -1506,7 +1608,7 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
         XWork &X = ctx->xw;
         rc = x_serialize_begin(ctx);
         if (rc) return rc;
-        HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync), s));
+        { const int rc_ = x_sync_reset(ctx, X.sync, 1, 4); if (rc_) return rc_; }
         XVfiArgs va{};
         va.c = c; va.V0 = V[0]; va.r = r; va.w = w; va.tr = tr; va.tol = tol; va.max_iter = max_iter; va.sy = X.sync; va.st_s = X.st_s;
         va.err = ctx->d_err; va.Vout = V[1]; va.pol = pol; va.iters = state; va.supnorm = norm;
@@ -1629,7 +1731,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
         XWork &X = ctx->xw;
         rc = x_serialize_begin(ctx);
         if (rc) return rc;
-        HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync), s));
+        { const int rc_ = x_sync_reset(ctx, X.sync, 1, 4); if (rc_) return rc_; }
         XStatArgs sa{};
         sa.c = c; sa.R = R; sa.D0 = D[0]; sa.tol = tol; sa.max_iter = max_iter; sa.check_every = check_every; sa.sy = X.sync;
         sa.st_D = X.st_D; sa.Dout = D[1]; sa.iters = state;

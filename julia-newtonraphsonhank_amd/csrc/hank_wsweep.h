@@ -33,6 +33,9 @@
 
 namespace hank {
 
+#ifndef HANK_WSLEEP
+#define HANK_WSLEEP 1      // dev knob: s_sleep units (64 clocks) between two polls of a wave
+#endif
 constexpr int WCH = 8;            // periods per staged chunk of the wave-uniform inputs (power of two)
 constexpr int WSB = 2;            // forward: batches of 64 source rows per round of a column
 
@@ -59,6 +62,21 @@ struct WRows {
 #pragma unroll
             for (int k = 0; k < PL; k++) {
                 const xv4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((el + k * ps) * 16u), 0, 16);
+                v[2 * k] = __hiloint2double((int)q.y, (int)q.x);
+                v[2 * k + 1] = __hiloint2double((int)q.w, (int)q.z);
+            }
+        }
+    }
+    // the same for the lanes with `on`; the others get zeros without a memory access (their offset is out of the buffer's
+    // range: the hardware bounds check returns zero) — no branch around a partly needed load
+    __device__ __forceinline__ void load_if(bool on, unsigned el, unsigned ps, double *v) const {
+        if constexpr (DW == 1) {
+            const xv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, on ? (int)(el * 8u) : (int)0xfffffff0u, 0, 16);
+            v[0] = __hiloint2double((int)q.y, (int)q.x);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PL; k++) {
+                const xv4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, on ? (int)((el + k * ps) * 16u) : (int)0xfffffff0u, 0, 16);
                 v[2 * k] = __hiloint2double((int)q.y, (int)q.x);
                 v[2 * k + 1] = __hiloint2double((int)q.w, (int)q.z);
             }
@@ -128,7 +146,7 @@ __device__ __forceinline__ bool wpoll(XSync *sy, int x, int k, int lo, int hi, u
             if (lane == 0) xfail(sy, XERR_TIMEOUT, x);
             return false;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(HANK_WSLEEP);
     }
 }
 // this wave's stores have reached L2 -> its episode becomes visible to the waves k of the other members
@@ -407,6 +425,208 @@ __global__ void __launch_bounds__(MAXT) k_wtan_back(WTanBackArgs A) {
             XSTAMP(0, son, i, 5);
             xlds_barrier();                             // the loader has landed the next trip's coefficients
             XSTAMP(0, son, i, 6);
+        }
+    }
+}
+
+// ---- version 3 of the backward slab sweep: the columns are a ROLLED loop -------------------------------------------------
+// The fully unrolled column bodies of k_wtan_back are 45-130 KB of code per instance (two CUs share a 64 KB instruction
+// cache) and keep dV of every column in registers (96 VGPRs at DW = 4). Here a column's dV takes the place of its ds_t in the
+// wave's LDS strip the moment the column's gathers have been read (same wave: LDS operations execute in order), the X half
+// loads the lane's own row back (all columns: the mixing is register-blocked per lane) and writes ds_{t-1} in place. The
+// record is read straight from global memory, software-pipelined two columns ahead; the halo rows one column ahead (a buffer
+// load whose lane offset is out of range returns zero without touching memory: no branch around the in-range lanes).
+// No loader wave, no workgroup barrier: every wave is on its own.
+static inline size_t vback_lds(int ne, int NEC, int DW, int NW) {
+    return sizeof(double) * ((size_t)NEC * NEC + NEC + 4 + (size_t)NW * (2 * WCH * (6 * DW + 2 + NEC) + (size_t)ne * 64 * DW));
+}
+
+template <int DW, int NEC, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_vtan_back(WTanBackArgs A) {
+    constexpr int UE = 6 * DW + 2 + NEC;
+    constexpr int VPL = (WCH * UE + 63) / 64;
+    constexpr int PL = WRows<DW>::PL;
+    extern __shared__ __attribute__((aligned(16))) double wl[];
+    const Consts &c = A.c;
+    const Record &R = A.R;
+    const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G, NW = A.NW;
+    double *PT = wl;                                    // [NEC][NEC]: PT[e][k] = Pi[e, k], zero beyond n_e
+    double *zsh = PT + NEC * NEC;
+    int *ctl = reinterpret_cast<int *>(zsh + NEC);
+    double *wave_all = zsh + NEC + 4;
+    const size_t WLDS = (size_t)2 * WCH * UE + (size_t)ne * 64 * DW;
+    for (int k = threadIdx.x; k < NEC * NEC; k += blockDim.x) {
+        const int e = k / NEC, kk = k - e * NEC;
+        PT[k] = (e < ne && kk < ne) ? c.Pi[e + ne * kk] : 0.0;
+    }
+    for (int k = threadIdx.x; k < NEC; k += blockDim.x) zsh[k] = k < ne ? c.z[k] : 0.0;
+    const XGroup g = xgroup_join(A.sy, ctl);
+    if (!g.ok) return;
+    const int x = g.x, cW = g.c;
+    if (x >= A.groups) return;
+    const int Sact = (na + XRW - 1) / XRW;
+    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
+    if (cW >= Sact) return;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slab = x * NW + wv;
+    if (slab * DW >= A.N) return;
+    const int r0 = cW * XRW, nown = min(XRW, na - r0);
+    const bool own = lane < nown;
+    const int a = r0 + (own ? lane : nown - 1);         // (idle lanes shadow the last row: no branches around them, their stores are masked)
+    double *uni = wave_all + (size_t)wv * WLDS;
+    double *strip = uni + 2 * WCH * UE;                 // [ne][64][DW]
+    const double xa = c.a[a];
+    const unsigned nslab = (unsigned)(A.groups * NW), rows = (unsigned)G;
+    WRows<DW> st;
+    st.init(A.st, (size_t)2 * nslab * PL * rows);
+    const unsigned hs = nslab * PL * rows, sb0 = (unsigned)slab * PL * rows;
+    const size_t dts = (size_t)nslab * PL * G, dsl = (size_t)slab * PL * G;
+
+    double sv[VPL];
+    auto stage_load = [&](int chunk) {
+#pragma unroll
+        for (int v = 0; v < VPL; v++) {
+            const int idx = lane + 64 * v;
+            double val = 0.0;
+            const int j = idx / UE, f = idx - j * UE, trip = chunk * WCH + j;
+            if (idx < WCH * UE && trip <= P) {
+                if (f < 6 * DW) {
+                    const int half = f / (3 * DW), ff = f - half * 3 * DW, which = ff / DW, d = ff - which * DW;
+                    const int per = half == 0 ? P - trip : P - 1 - trip, n = slab * DW + d;
+                    if (per >= 0 && per < P && n < A.N && (which < 2 || c.n_hh > 2)) {
+                        const double *sp = which == 0 ? A.dxr : (which == 1 ? A.dxw : A.dxt);
+                        val = sp[(size_t)per * A.Ntot + A.n0 + n];
+                    }
+                } else if (f == 6 * DW) {
+                    if (P - 1 - trip >= 0) val = A.rho[P - 1 - trip];
+                } else if (f == 6 * DW + 1) {
+                    int s = (Sact - 1) << 8, r = (Sact - 1) << 8;
+                    const int tY = P - trip;
+                    if (A.src && tY >= 0 && tY < P) s = A.src[(size_t)tY * Sact + cW];
+                    if (A.rdr && tY + 1 >= 0 && tY + 1 < P) r = A.rdr[(size_t)(tY + 1) * Sact + cW];
+                    val = __hiloint2double(r, s);
+                } else {
+                    const int e = f - (6 * DW + 2), tx = P - 1 - trip;
+                    int2 pb = make_int2(na, -1);
+                    if (A.pub && tx >= 0 && e < ne) pb = A.pub[((size_t)tx * Sact + cW) * 16 + e];
+                    val = __hiloint2double(pb.y, pb.x);
+                }
+            }
+            sv[v] = val;
+        }
+    };
+    auto stage_write = [&](int chunk) {
+#pragma unroll
+        for (int v = 0; v < VPL; v++) {
+            const int idx = lane + 64 * v;
+            if (idx < WCH * UE) uni[(chunk & 1) * WCH * UE + idx] = sv[v];
+        }
+    };
+    stage_load(0);
+    stage_write(0);
+    {   // dV_T = 0 (BackwardIteration.jl:85)
+        double z[DW];
+#pragma unroll
+        for (int d = 0; d < DW; d++) z[d] = 0.0;
+        for (int e = 0; e < ne; e++) wstrip_store<DW>(strip + ((size_t)e * 64 + lane) * DW, z);
+    }
+    struct Co { double A, B, u, v; int ib; };
+    for (int i = 0; i <= P; i++) {
+        const int ci = i / WCH, ji = i - ci * WCH;
+        if (ji == 0) stage_load(ci + 1);
+        if (ji == WCH / 2) stage_write(ci + 1);
+        const double *U = uni + ((size_t)(ci & 1) * WCH + ji) * UE;
+        const double rng = U[6 * DW + 1];
+        const int rs_ = __builtin_amdgcn_readfirstlane(__double2loint(rng)), rr_ = __builtin_amdgcn_readfirstlane(__double2hiint(rng));
+        if (i > 0) {
+            // ---- Y-tangent of period t, column by column: dg = A ds[ib] + B ds[ib+1]; dV = u dr + v ((a dr + z dw + dtr) - dg)
+            const int t = P - i;
+            const unsigned cur = (unsigned)((i - 1) & 1) * hs + sb0;
+            const size_t ro = (size_t)t * G + a;
+            auto fetch = [&](int e) {
+                Co q;
+                const size_t p_ = ro + (size_t)(e < ne ? e : ne - 1) * na;
+                q.A = R.A[p_]; q.B = R.B[p_]; q.u = R.u[p_]; q.v = R.v[p_]; q.ib = R.ib[p_];
+                return q;
+            };
+            double h0[DW], h1[DW];                      // the halo rows of the NEXT column (zero where the row is the wave's own)
+            auto halo = [&](int e, const Co &q, double *o0, double *o1) {
+                const int q0 = q.ib - r0, q1 = q0 + 1;
+                const bool live = q.A != 0.0 || q.B != 0.0;
+                const unsigned el = cur + (unsigned)(e * na + q.ib);
+                st.load_if(live && !(q0 >= 0 && q0 < nown), el, rows, o0);
+                st.load_if(live && !(q1 >= 0 && q1 < nown), el + 1, rows, o1);
+            };
+            if (!wpoll(A.sy, x, wv, rs_ & 255, (rs_ >> 8) & 255, (unsigned)i)) return;
+            double dr[DW], dw[DW], dt[DW], xdr[DW];
+#pragma unroll
+            for (int d = 0; d < DW; d++) { dr[d] = U[d]; dw[d] = U[DW + d]; dt[d] = U[2 * DW + d]; xdr[d] = xa * dr[d]; }
+            Co c0 = fetch(0), c1 = fetch(1);
+            halo(0, c0, h0, h1);
+            for (int e = 0; e < ne; e++) {
+                const Co c2 = fetch(e + 2);
+                double n0[DW], n1[DW];
+                halo(e + 1 < ne ? e + 1 : e, c1, n0, n1);
+                // this column: own rows from the strip, the rest from the halo loads issued a column ago
+                const int q0 = c0.ib - r0, q1 = q0 + 1;
+                const bool in0 = q0 >= 0 && q0 < nown, in1 = q1 >= 0 && q1 < nown;
+                double s0[DW], s1[DW], dg[DW], dV[DW];
+                wstrip_load<DW>(strip + ((size_t)e * 64 + (in0 ? q0 : 0)) * DW, s0);
+                wstrip_load<DW>(strip + ((size_t)e * 64 + (in1 ? q1 : 0)) * DW, s1);
+                const bool live = c0.A != 0.0 || c0.B != 0.0;
+                const double ze = zsh[e];
+#pragma unroll
+                for (int d = 0; d < DW; d++) {
+                    const double d0 = in0 ? s0[d] : h0[d], d1 = in1 ? s1[d] : h1[d];
+                    dg[d] = live ? c0.A * d0 + c0.B * d1 : 0.0;
+                    dV[d] = c0.u * dr[d] + c0.v * ((xdr[d] + (ze * dw[d] + dt[d])) - dg[d]);
+                }
+                wstrip_store<DW>(strip + ((size_t)e * 64 + lane) * DW, dV);      // (after the gathers of this column: same wave, in order)
+                if (own) wstream_store<DW>(A.dpol, (size_t)t * dts + dsl + (size_t)e * na + a, (size_t)G, dg);
+#pragma unroll
+                for (int d = 0; d < DW; d++) { h0[d] = n0[d]; h1[d] = n1[d]; }
+                c0 = c1; c1 = c2;
+            }
+        }
+        if (i < P) {
+            // ---- X-tangent of period tx: the lane's own row of dV (all columns) back into registers, ds in place
+            const int tx = P - 1 - i;
+            double v[NEC][DW];
+#pragma unroll
+            for (int k = 0; k < NEC; k++) {
+                if (k < ne) wstrip_load<DW>(strip + ((size_t)k * 64 + lane) * DW, v[k]);
+                else {
+#pragma unroll
+                    for (int d = 0; d < DW; d++) v[k][d] = 0.0;
+                }
+            }
+            double dr1[DW], dw1[DW], dt1[DW];
+#pragma unroll
+            for (int d = 0; d < DW; d++) { dr1[d] = U[3 * DW + d]; dw1[d] = U[4 * DW + d]; dt1[d] = U[5 * DW + d]; }
+            const double rho = U[6 * DW];
+            const size_t rx = (size_t)tx * G + a;
+            double ck = R.kc[rx], cs = R.s[rx];
+            if (i >= 2 && !wpoll(A.sy, x, wv, rr_ & 255, (rr_ >> 8) & 255, (unsigned)i)) return;
+            for (int e = 0; e < ne; e++) {
+                const size_t pn = rx + (size_t)(e + 1 < ne ? e + 1 : e) * na;
+                const double ckn = R.kc[pn], csn = R.s[pn];
+                double mx[DW], ds[DW];
+                const double *pt = PT + e * NEC;
+#pragma unroll
+                for (int k = 0; k < NEC; k++) {
+                    const double p = pt[k];
+#pragma unroll
+                    for (int d = 0; d < DW; d++) mx[d] = k == 0 ? p * v[k][d] : mx[d] + p * v[k][d];
+                }
+                const double ze = zsh[e], pbv = U[6 * DW + 2 + e];
+                const int pbL = __double2loint(pbv), pbH = __double2hiint(pbv);
+#pragma unroll
+                for (int d = 0; d < DW; d++) ds[d] = ck * mx[d] - rho * ((ze * dw1[d] + dt1[d]) + cs * dr1[d]);
+                wstrip_store<DW>(strip + ((size_t)e * 64 + lane) * DW, ds);
+                if (own && (a <= pbL || a >= pbH)) st.store((unsigned)(i & 1) * hs + sb0 + (unsigned)(e * na + a), rows, ds);
+                ck = ckn; cs = csn;
+            }
+            wpublish(A.sy, x, cW, wv, (unsigned)(i + 1));
         }
     }
 }

@@ -164,6 +164,11 @@ __device__ inline void xfail(XSync *sy, unsigned code, int x) {
         __hip_atomic_store(&sy->status[1], (unsigned)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// dev knob HANK_XFAULT: the status word of a launch's sync block pre-set by the host
+__global__ void k_xpoison(XSync *base, int count, unsigned code) {
+    if ((int)threadIdx.x < count) { base[threadIdx.x].status[0] = code; base[threadIdx.x].status[1] = 0u; }
+}
+
 // which XCD am I on, which member of its group am I, how many members does it have (known once EVERY workgroup of the
 // launch holds a ticket: one launch-wide wait at the start of the sweep, none afterwards)
 __device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
@@ -171,16 +176,20 @@ __device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
         int xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 7;
-        const unsigned c = __hip_atomic_fetch_add(&sy->ticket[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the ticket is taken before it is counted
-        __hip_atomic_fetch_add(&sy->total[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 1;
-        for (unsigned spins = 0;; spins++) {
-            if (xldu(&sy->total[0]) >= gridDim.x) break;
-            if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) { xfail(sy, XERR_TIMEOUT, xcc); ok = 0; break; }
-            __builtin_amdgcn_s_sleep(2);
+        if (xldu(&sy->status[0]) != 0u) {       // the launch is already marked failed (a sibling gave up; the dev knob): leave at once
+            ctl[0] = xcc; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0;
+        } else {
+            const unsigned c = __hip_atomic_fetch_add(&sy->ticket[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the ticket is taken before it is counted
+            __hip_atomic_fetch_add(&sy->total[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int ok = 1;
+            for (unsigned spins = 0;; spins++) {
+                if (xldu(&sy->total[0]) >= gridDim.x) break;
+                if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) { xfail(sy, XERR_TIMEOUT, xcc); ok = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            ctl[0] = xcc; ctl[1] = (int)c; ctl[2] = (int)xldu(&sy->ticket[xcc][0]); ctl[3] = ok;
         }
-        ctl[0] = xcc; ctl[1] = (int)c; ctl[2] = (int)xldu(&sy->ticket[xcc][0]); ctl[3] = ok;
     }
     __syncthreads();
     XGroup g;

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
     "hank_primal_jvp", "hank_primal_jvp_dev",
     "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
-    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings", "hank_stats", "hank_vfi", "hank_stationary_dist", "hank_device_available",
+    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings", "hank_stats", "hank_vfi", "hank_stationary_dist", "hank_fake_news", "hank_device_available",
 )
 
 
@@ -104,6 +104,7 @@ def load_library() -> C.CDLL:
     lib.hank_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.hank_vfi.argtypes = [vp, dp, C.c_double, i32, dp, dp, C.POINTER(i32), dp]
     lib.hank_stationary_dist.argtypes = [vp, dp, dp, C.c_double, i32, i32, C.POINTER(i32)]
+    lib.hank_fake_news.argtypes = [vp, dp, dp]
     lib.hank_device_available.argtypes = []
     for name in ABI_SYMBOLS:
         if name != "hank_last_error":
@@ -284,6 +285,14 @@ class HouseholdBlock:
         out = np.empty((self.n_a, self.n_e, self.P, N), order="F")
         self._chk(self._lib.hank_get_dpolicy_seq(self._ctx, int(N), _p(out)))
         return out
+
+    def fake_news(self):
+        """the household block's Jacobian at the steady state from its Toeplitz structure (hank_fake_news):
+        -> F (P, P, n_hh), Dv (P, n_hh); `SteadyStateJacobian.household_jacobian` turns them into d agg_t / d xhh_{k,s}."""
+        F = np.empty((self.P, self.P, self.n_hh), order="F")
+        Dv = np.empty((self.P, self.n_hh), order="F")
+        self._chk(self._lib.hank_fake_news(self._ctx, _p(F), _p(Dv)))
+        return F, Dv
 
     def vfi(self, value0, xhh_t, tol: float, max_iter: int = 10_000):
         """device-resident inner fixed point of the steady state (hank_vfi; SteadyState.jl:132-141):

@@ -126,6 +126,27 @@ if __name__ == "__main__":
         timing(2000, 11, 300, [int(v) for v in sys.argv[2:]] or [32], envs=(COL,), reps=5)
     if what == "slab":
         timing(2000, 11, 300, [int(v) for v in sys.argv[2:]] or [256], envs=(SL,), reps=3)
+    if what == "v3":
+        V3 = dict(SL, HANK_W_V3=1)
+        parity(130, 3, 20, 9, envs=(V3, dict(V3, HANK_W_DW=1, HANK_W_NW=2), dict(V3, HANK_W_DW=4, HANK_W_NW=1)))
+        parity(200, 7, 40, 32, envs=(V3, dict(V3, HANK_W_DW=4, HANK_W_NW=1)))
+        parity(40, 16, 8, 6, envs=(V3,))
+        parity(37, 3, 9, 70, envs=(V3,))
+        parity(2000, 11, 300, 128, shock=0.01, envs=(V3, dict(V3, HANK_W_DW=2, HANK_W_NW=7), dict(V3, HANK_W_DW=4, HANK_W_NW=6), dict(V3, HANK_W_ALLROWS=1)))
+        def E(dw, nw, **kw):
+            return dict(V3, HANK_W_DW=dw, HANK_W_NW=nw, **kw)
+        timing(2000, 11, 300, [1], envs=(E(1, 1),))
+        timing(2000, 11, 300, [32], envs=(E(4, 1), E(2, 2), E(1, 4)))
+        timing(2000, 11, 300, [128], envs=(E(4, 4), E(2, 7), E(2, 8)))
+        timing(2000, 11, 300, [192], envs=(E(4, 6), E(4, 5)))
+        timing(2000, 11, 300, [256], envs=(E(4, 4), E(4, 6), E(2, 8)))
+    if what == "v3t":
+        V3 = dict(SL, HANK_W_V3=1)
+        def E(dw, nw, **kw):
+            return dict(V3, HANK_W_DW=dw, HANK_W_NW=nw, **kw)
+        timing(2000, 11, 300, [1], envs=(E(1, 1),))
+        timing(2000, 11, 300, [32], envs=(E(2, 2),))
+        timing(2000, 11, 300, [128], envs=(E(4, 4), E(2, 7)))
     if what == "tune":
         def E(dw, nw, **kw):
             return dict(SL, HANK_W_DW=dw, HANK_W_NW=nw, **kw)

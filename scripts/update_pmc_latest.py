@@ -22,5 +22,9 @@ wl = d.setdefault("ks_2000x11_T300_N32", {})
 for k in ("k_fused_back", "k_fused_fwd"):
     f, w = 2.0 * mean_kb("FETCH_SIZE", k) * 1024, mean_kb("WRITE_SIZE", k) * 1024
     wl[k] = {"fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w, "note": note}
+sys.path.insert(0, str(root.parent))
+from bench import kernel_source_sha16  # noqa: E402
+wl["kernel_source_sha16"] = kernel_source_sha16()
+wl["profile_tag"] = tag
 p.write_text(json.dumps(d, indent=1))
 print(json.dumps({k: wl[k]["hbm_bytes"] for k in ("k_fused_back", "k_fused_fwd")}))

@@ -1,0 +1,96 @@
+"""The steady-state Jacobian from its Toeplitz structure (hank_fake_news + the reference's recursion,
+SteadyStateJacobian.jl:187-256, :293-323, :358-387) against the same matrix assembled column by column from unit-tangent
+JVPs of the full pipeline (method="columns", itself checked against the oracle in test_gpu_api.py). Tolerance: 1e-8 of the
+largest entry (observed 5e-10 .. 1.3e-9) — the two differ only by how stationary the recorded steady state is (VFI tolerance
+1e-11) and by summation order."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ks_setup
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+@pytest.mark.parametrize("n_a,n_e,T", [(50, 2, 100), (500, 4, 300), (130, 3, 20)])
+def test_toeplitz_jacobian_equals_the_unit_tangent_jacobian(hank, n_a, n_e, T):
+    m, ss, _ = ks_setup(n_a, n_e, T)
+    Jt = hank.getSteadyStateJacobian(ss, m, method="toeplitz").toarray()
+    Jc = hank.getSteadyStateJacobian(ss, m, method="columns").toarray()
+    assert Jt.shape == Jc.shape == (4 * (T - 1), 4 * (T - 1))
+    assert np.max(np.abs(Jc)) > 0.5
+    assert np.max(np.abs(Jt - Jc)) < 1e-8 * np.max(np.abs(Jc))
+    # the household block's own Jacobian, entry by entry: d KD_t / d r_s and d KD_t / d w_s from unit tangents
+    from hank_amd.SteadyStateJacobian import household_jacobian
+    from hank_amd.BackwardIteration import household_block
+    hb = household_block(m)
+    P = T - 1
+    x = np.tile(np.array([[ss.vars["r"]], [ss.vars["w"]]]), (1, P))
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(x)
+    Jhh = household_jacobian(*hb.fake_news())
+    assert Jhh.shape == (2, P, P)
+    cols = [0, 1, P // 2, P - 2, P - 1]
+    y = np.zeros((2, P, 2 * len(cols)))
+    for q, s_ in enumerate(cols):
+        y[0, s_, 2 * q] = 1.0
+        y[1, s_, 2 * q + 1] = 1.0
+    d = hb.jvp(y)
+    for q, s_ in enumerate(cols):
+        assert np.max(np.abs(d[:, 2 * q] - Jhh[0][:, s_])) < 1e-9 * max(1.0, np.max(np.abs(d)))
+        assert np.max(np.abs(d[:, 2 * q + 1] - Jhh[1][:, s_])) < 1e-9 * max(1.0, np.max(np.abs(d)))
+
+
+def test_toeplitz_jacobian_one_asset_hank(hank):
+    """three household inputs, leads and lags in the equations around the block"""
+    from examples.solve_hank import build
+    m, ss = build(80, 3, 40)
+    Jt = hank.getSteadyStateJacobian(ss, m, method="toeplitz").toarray()
+    Jc = hank.getSteadyStateJacobian(ss, m, method="columns").toarray()
+    assert np.max(np.abs(Jt - Jc)) < 1e-8 * max(1.0, np.max(np.abs(Jc)))
+
+
+def test_fake_news_needs_a_recorded_primal(hank):
+    m, ss, _ = ks_setup(50, 2, 100)
+    wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    hb = hank.HouseholdBlock(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+    hb.set_boundary(ss.value, ss.D)
+    with pytest.raises(hank.HankHIPError):
+        hb.fake_news()
+    hb.close()
+
+
+def test_newton_with_the_toeplitz_preconditioner(hank):
+    """the converged path does not depend on which branch built J̅"""
+    m, ss, _ = ks_setup(50, 2, 60)
+    P = 59
+    Z = 1.0 + 0.01 * 0.8 ** np.arange(1, P + 1)
+    x0 = np.tile(np.array([ss.vars[k] for k in ("Y", "KS", "r", "w")]), P)
+    xs = [hank.NewtonRaphsonHANK(x0, hank.getSteadyStateJacobian(ss, m, method=meth), {"Z": Z}, m, ss, ss, ε=1e-9) for meth in ("toeplitz", "columns")]
+    assert np.max(np.abs(xs[0] - xs[1])) < 1e-8
+
+
+def test_krylov_inner_loop_reaches_the_same_path_with_fewer_jvps(hank):
+    """opt-in inner="krylov" (GMRES on J(x), right-preconditioned by the steady-state Jacobian) against the reference's damped
+    fixed point (α = 0.5 hard-coded, NewtonRaphson.jl:102): same converged path to 1e-8, a fraction of the JVPs; and a passed
+    α is honoured (α = 1: the undamped iteration, fewer inner steps than α = 0.5)."""
+    m, ss, _ = ks_setup(50, 2, 60)
+    P = 59
+    Z = 1.0 + 0.01 * 0.8 ** np.arange(1, P + 1)
+    x0 = np.tile(np.array([ss.vars[k] for k in ("Y", "KS", "r", "w")]), P)
+    J = hank.getSteadyStateJacobian(ss, m)
+    out = {}
+    for name, kw in (("reference", {}), ("krylov", {"inner": "krylov"}), ("undamped", {"α": 1.0})):
+        hank.y_Iteration.total_jvps = 0
+        x = hank.NewtonRaphsonHANK(x0, J, {"Z": Z}, m, ss, ss, ε=1e-9, **kw)
+        out[name] = (x, hank.y_Iteration.total_jvps, hank.NewtonRaphsonHANK.iterations)
+        lin = hank.LinearizedFunction(x, {"Z": Z}, m, ss, ss)
+        assert np.linalg.norm(lin.Fx) < 1e-8
+    assert np.max(np.abs(out["krylov"][0] - out["reference"][0])) < 1e-8
+    assert np.max(np.abs(out["undamped"][0] - out["reference"][0])) < 1e-8
+    assert out["krylov"][1] < out["reference"][1] / 2
+    assert out["undamped"][1] < out["reference"][1]

@@ -168,3 +168,68 @@ def test_power_method_stops_only_when_every_member_has_converged(hank, monkeypat
         hb.close()
     assert out["xcd"][1] == 800 and out["launch"][1] == 800               # the rule first holds at the 32nd check
     assert np.max(np.abs(out["xcd"][0] - out["launch"][0])) < 1e-13
+
+
+def _oracle_vfi(orc, shape, r, w, tol, cap=20_000):
+    """the reference's inner fixed point (SteadyState.jl:132-141) on the CPU oracle's ValueFunction: value <- value_fn(value).Value
+    from ones until max|new - old| < tol; returns (value, policy, steps, per-step sup-norms)."""
+    value = np.ones(shape)
+    norms = []
+    for k in range(1, cap + 1):
+        st, V, KD = orc.value_function(value, r, w, 1)
+        assert st == 0
+        vn, pol = V[..., 0], KD[..., 0]
+        norms.append(float(np.max(np.abs(vn - value))))
+        value = vn
+        if norms[-1] < tol:
+            return value, pol, k, norms
+    raise AssertionError("oracle VFI did not converge")
+
+
+@pytest.mark.parametrize("n_a,n_e,T", [(50, 2, 100), (37, 3, 9)])
+def test_device_vfi_matches_the_oracle_iteration(hank, monkeypatch, n_a, n_e, T):
+    """hank_vfi (both schedules) against oracle/ — the C restatement of KrusellSmith.jl:43-83 iterated with the reference's
+    stopping rule: the same number of steps, value and policy to rel 1e-10 (SURVEY.md 8c tolerance)."""
+    m, ss, orc = ks_setup(n_a, n_e, T)
+    r, w, tol = ss.vars["r"], ss.vars["w"], 1e-11
+    v_o, p_o, steps_o, _ = _oracle_vfi(orc, (n_a, n_e), r, w, tol)
+    wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    for sched in ("launch", "xcd"):
+        monkeypatch.setenv("HANK_SCHEDULE", sched)
+        hb = hank.HouseholdBlock(wd.grid, pdm.grid, pdm.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+        v, pol, it, nrm = hb.vfi(np.ones((n_a, n_e)), [r, w], tol)
+        assert abs(it - steps_o) <= 1 and nrm < tol, (sched, it, steps_o)      # (a sup-norm within rounding of tol may tip one step)
+        assert np.max(np.abs(v - v_o)) < 1e-10 * np.abs(v_o).max()
+        assert np.max(np.abs(pol - p_o)) < 1e-10 * max(1.0, np.abs(p_o).max())
+        hb.close()
+
+
+def test_value_iteration_stops_only_when_every_member_has_converged(hank, monkeypatch):
+    """the twin of the power-method case above for k_xvfi's vote: at r = 1.5 %, w = 1 the marginal value of the rich keeps
+    moving long after the bottom of the grid has settled — member 0's 63 rows pass max|Δ| < tol at step 662, the top member at
+    818 (on the oracle). A vote that looked at member 0 only would stop 156 steps early. The persistent loop, the launched
+    loop and the oracle iteration must all stop in the step in which the LAST rows pass, and agree on value and policy."""
+    m, ss, orc = ks_setup(500, 4, 300)
+    wd, pdm = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    r, w, tol = 0.015, 1.0, 1e-10
+    v_o, p_o, steps_o, norms = _oracle_vfi(orc, (500, 4), r, w, tol)
+    # the members really do converge at different times: the first 63 rows pass the rule long before the whole grid does
+    value = np.ones((500, 4)); first = None
+    for k in range(1, steps_o + 1):
+        st, V, _ = orc.value_function(value, r, w, 1)
+        d = np.abs(V[..., 0] - value); value = V[..., 0]
+        if first is None and np.max(d[:63]) < tol:
+            first = k
+    assert first is not None and first < steps_o - 100, (first, steps_o)
+    out = {}
+    for sched in ("launch", "xcd"):
+        monkeypatch.setenv("HANK_SCHEDULE", sched)
+        hb = hank.HouseholdBlock(wd.grid, pdm.grid, pdm.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
+        out[sched] = hb.vfi(np.ones((500, 4)), [r, w], tol)
+        assert hb.stats()["fallbacks"] == 0
+        hb.close()
+    assert out["xcd"][2] == out["launch"][2]
+    assert abs(out["xcd"][2] - steps_o) <= 1
+    for sched in out:
+        assert np.max(np.abs(out[sched][0] - v_o)) < 1e-10 * np.abs(v_o).max()
+        assert np.max(np.abs(out[sched][1] - p_o)) < 1e-10 * max(1.0, np.abs(p_o).max())

@@ -142,3 +142,85 @@ def test_flatten_unflatten_roundtrip():
     Tv = shape[0] * shape[1]
     back = [flat[i * Tv:(i + 1) * Tv].reshape(shape, order="F") for i in range(P)]
     assert len(flat) == Tv * P and all(np.array_equal(a, b) for a, b in zip(seqs["KD"], back))
+
+
+def test_household_jacobian_recursion_is_the_closed_form():
+    """J[t, s] = [t <= s] Dv[s - t] + sum_{tau <= min(t, s)} F[t - tau, s - tau]  (SteadyStateJacobian.jl:363-371)"""
+    from hank_amd.SteadyStateJacobian import household_jacobian
+    rng = np.random.default_rng(5)
+    P, K = 9, 2
+    F, Dv = rng.standard_normal((P, P, K)), rng.standard_normal((P, K))
+    J = household_jacobian(F, Dv)
+    for k in range(K):
+        for t in range(P):
+            for s in range(P):
+                ref = (Dv[s - t, k] if t <= s else 0.0) + sum(F[t - tau, s - tau, k] for tau in range(min(t, s) + 1))
+                assert abs(J[k, t, s] - ref) < 1e-12
+
+
+def test_direct_blocks_reproduce_the_residual_layer():
+    """the equations' own Jacobian blocks (SteadyStateJacobian.jl:124-145) placed on the block diagonals equal the JVP of
+    assemble_full_xMat + Residuals with the aggregates held fixed, column by column"""
+    import hank_amd as h
+    from hank_amd.Aggregation import Residuals
+    from hank_amd.dual import Dual
+    from hank_amd.GeneralStructures import assemble_full_xMat, var_names, vars_of_type
+    from hank_amd.SteadyStateJacobian import direct_blocks
+    from tests.conftest import ks_setup  # noqa: F401
+    m, ss, _ = ks_setup(50, 2, 12)
+    cs = m.compspec
+    P, n_endog, n_eq = cs.T - 1, cs.n_endog, len(m.equations)
+    keys, ek = var_names(m), vars_of_type(m, "endogenous")
+    B = direct_blocks(m, ss)
+    J4 = np.zeros((P, n_eq, P, n_endog))
+    tt = np.arange(P)
+    for o, Bo in B.items():
+        ok = (tt + o >= 0) & (tt + o < P)
+        for j, k in enumerate(ek):
+            J4[tt[ok], :, tt[ok] + o, j] += Bo[:, keys.index(k)][None, :]
+    J = J4.reshape(P * n_eq, P * n_endog)
+    n = n_endog * P
+    x = np.tile(np.array([ss.vars[k] for k in ek]), P)
+    xd = Dual.seed(x, np.eye(n))
+    exog = {k: np.full(P, float(ss.vars[k])) for k in vars_of_type(m, "exogenous")}
+    agg = {k: np.full(P, float(ss.vars[k])) for k in vars_of_type(m, "heterogeneous")}
+    res = Residuals(assemble_full_xMat(xd, agg, exog, m, ss, ss), m)
+    assert np.max(np.abs(res.p - J)) < 1e-12
+
+
+def test_device_group_shards_columns_contiguously():
+    """one process, one context per GPU (parallel.DeviceGroup over hank_create_on): the column blocks of shard_bounds, in
+    order, assembled on the host — with stand-in contexts (no GPU here)."""
+    from hank_amd.parallel import DeviceGroup, shard_bounds
+
+    class Fake:
+        def __init__(self, device=0):
+            self.device, self.seen = device, []
+
+        def clone(self, device=None):
+            return Fake(device)
+
+        def set_boundary(self, v, D):
+            self.b = (v, D)
+
+        def primal(self, x):
+            return np.asarray(x).sum(axis=0)
+
+        def jvp(self, y):
+            self.seen.append(y.shape[2])
+            return y[0] * (1 + self.device)            # (P, k), tagged by the device that computed it
+
+        def close(self):
+            pass
+
+    g = DeviceGroup(Fake(0), [0, 1, 2])
+    assert [b.device for b in g.blocks] == [0, 1, 2]
+    g.set_boundary(1.0, 2.0)
+    y = np.arange(2 * 5 * 8, dtype=float).reshape(2, 5, 8)
+    out = g.jvp(y)
+    assert out.shape == (5, 8)
+    for r in range(3):
+        lo, hi = shard_bounds(8, 3, r)
+        assert np.array_equal(out[:, lo:hi], y[0][:, lo:hi] * (1 + r))
+    assert [b.seen for b in g.blocks] == [[3], [3], [2]]
+    g.close()
