@@ -5,7 +5,6 @@
 // and the 2(T-1) dependent launches are replayed from hipGraphs (no host launch cost).
 #include "hank_kernels.h"
 #include "hank_xsweep.h"
-#include "hank_wsweep.h"
 #include "hank_jacobian.h"
 #include "../../include/hank_hip.h"
 
@@ -60,12 +59,9 @@ struct TanWork {
 // ---- XCD-local persistent sweeps (hank_xsweep.h): per-context workspace and per-batch-width tangent buffers ----
 constexpr int XD_MAX = 4;           // directions per group and pass (D = 8 spills registers: wider batches run as passes)
 constexpr int XPASS_MAX = 64;       // passes per call: N <= 8 * XD_MAX * XPASS_MAX = 2048 directions
-struct XPass { int n0, N, D, groups; size_t dpol_off; int NW; };     // NW > 0: slab sweeps (hank_wsweep.h), NW waves of D directions per member
+struct XPass { int n0, N, D, groups; size_t dpol_off; };
 struct XTan {                       // one per batch width N (kept in a small LRU: Jacobian assembly and Newton alternate widths)
     int N = 0;
-    bool slab = false;              // the passes run as slab sweeps
-    double *st_b = nullptr, *st_f = nullptr;      // slab sweeps: the ping-pong state of the widest pass
-    int Wmax = 0;
     std::vector<XPass> passes;
     double *dxhh = nullptr, *dxr = nullptr, *dxw = nullptr, *dxt = nullptr;   // staging + [P][N] input tangents
     double *dpol = nullptr;         // per pass [P][groups][G][D]
@@ -81,8 +77,6 @@ struct XWork {
     double *st_s = nullptr, *st_ds = nullptr, *st_D = nullptr, *st_dD = nullptr;
     double *Dvirt = nullptr, *aggpart = nullptr, *rho = nullptr;
     int *srcB = nullptr, *srcF = nullptr;     // [P][Sact] source-member ranges of the tangent sweeps at the recorded primal
-    int *rdrB = nullptr, *rdrF = nullptr;     // [P][Sact] the inverse: which members read a member's rows
-    int2 *pubB = nullptr;                     // [P][Sact][16] backward slab sweep: which rows a member stores to L2 (k_wpub_back)
     int lds_max = 65536;
     int fault_where = 7;
     int fault = 0;                            // dev knob HANK_XFAULT=placement: every persistent launch finds its status word set ("a
@@ -119,6 +113,7 @@ struct hank_ctx {
     // 0 = one launch per period for everything; 1 = XCD-local persistent sweeps for everything; 2 = auto (default where
     // the persistent sweeps are supported): each entry point takes the faster of the two for its shape — see sched_*
     int schedule = 2;
+    bool forced_xcd = false;       // HANK_SCHEDULE=xcd at hank_create: no silent fallback to the launches
     int last_tan = 0;              // which implementation ran the last tangent sweep (0 launches, 1 persistent): hank_get_dpolicy_seq
     int xjvp_max = 64;             // auto: batches up to this width take the persistent tangent sweeps (measured crossover)
     XWork xw;
@@ -421,7 +416,16 @@ static int fetch_device_error(hank_ctx *ctx) {
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e[0] == 0) return ctx->schedule >= 1 ? x_status(ctx) : HANK_OK;
+    if (ctx->schedule >= 1) {
+        // a persistent sweep that did not run (its groups did not form, a wait timed out) leaves the record unwritten: what
+        // the kernels behind it then found in it (a "non-monotone policy", say) is not an error of the model — report the sweep
+        const int xs = x_status(ctx);
+        if (xs) {
+            if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
+            return xs;
+        }
+    }
+    if (e[0] == 0) return HANK_OK;
     ctx->primal_done = false;
     HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));      // reported once: the next call starts clean
     switch (e[0]) {
@@ -471,7 +475,6 @@ static bool x_supported(const hank_ctx *ctx, int cus, size_t lds_max) {
 static void x_free_tan(XTan &w) {
     (void)hipFree(w.dxhh); (void)hipFree(w.dxr); (void)hipFree(w.dxw); (void)hipFree(w.dxt);
     (void)hipFree(w.dpol); (void)hipFree(w.daggpart); (void)hipFree(w.dagg_pass); (void)hipFree(w.dagg_cm);
-    (void)hipFree(w.st_b); (void)hipFree(w.st_f);
     w = XTan();
 }
 
@@ -482,7 +485,6 @@ static void x_free(hank_ctx *ctx) {
     ctx->xcur = nullptr;
     (void)hipFree(X.sync); (void)hipFree(X.st_s); (void)hipFree(X.st_ds); (void)hipFree(X.st_D); (void)hipFree(X.st_dD);
     (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart); (void)hipFree(X.rho); (void)hipFree(X.srcB); (void)hipFree(X.srcF);
-    (void)hipFree(X.rdrB); (void)hipFree(X.rdrF); (void)hipFree(X.pubB);
     X = XWork();
 }
 
@@ -510,9 +512,6 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.rho, P));
     HIPC(ctx, dmalloc(&X.srcB, P * X.Sact));
     HIPC(ctx, dmalloc(&X.srcF, P * X.Sact));
-    HIPC(ctx, dmalloc(&X.rdrB, P * X.Sact));
-    HIPC(ctx, dmalloc(&X.rdrF, P * X.Sact));
-    HIPC(ctx, dmalloc(&X.pubB, P * X.Sact * 16));
     X.lds_max = (int)prop.sharedMemPerBlock;
     if (const char *xf = getenv("HANK_XFAULT")) {      // "placement" | "timeout", optionally ":primal" | ":tangent" | ":fixedpoint" (default: every persistent launch)
         X.fault = strncmp(xf, "placement", 9) == 0 ? XERR_PLACEMENT : (strncmp(xf, "timeout", 7) == 0 ? XERR_TIMEOUT : 0);
@@ -522,28 +521,6 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, hipMemset(X.Dvirt, 0, sizeof(double) * P * c.n_e * 64));
     X.ready = true;
     return HANK_OK;
-}
-
-// which persistent tangent sweeps run: the column-wave sweeps (hank_xsweep.h) or the slab sweeps (hank_wsweep.h, HANK_XTAN=slab)
-static bool x_use_slab() {
-    const char *e = getenv("HANK_XTAN");
-    return e && strcmp(e, "slab") == 0;
-}
-static int w_nec(const hank_ctx *ctx) { return (ctx->c.n_e + 3) / 4 * 4; }
-// directions per wave (DW) and waves per member (NW) for a pass over the next n directions (8 groups x NW x DW per pass);
-// dev knobs HANK_W_DW / HANK_W_NW
-static void w_plan(const hank_ctx *ctx, int n, int &DW, int &NW) {
-    if (n <= 8) { DW = 1; NW = 1; }
-    else if (n <= 16) { DW = 2; NW = 1; }
-    else if (n <= 32) { DW = 2; NW = 2; }
-    else if (n <= 64) { DW = 4; NW = 2; }
-    else { DW = 4; NW = 4; }
-    if (w_nec(ctx) > 12 && DW == 4) { DW = 2; NW = std::min(7, NW * 2); }     // 16 columns x 4 directions do not fit the registers
-    if (const char *e = getenv("HANK_W_DW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) DW = v; }
-    if (const char *e = getenv("HANK_W_NW")) { const int v = atoi(e); if (v >= 1 && v <= 7) NW = v; }      // + the loader wave: 8 waves, two per SIMD
-    // the strips of the waves' own rows and the coefficient ring must fit the CU's LDS
-    const int ne = ctx->c.n_e, NEC = w_nec(ctx);
-    while (NW > 1 && (int)std::max(wfwd_lds(ne, NEC, DW, NW), wback_lds(ne, NEC, DW, NW)) > ctx->xw.lds_max) NW--;
 }
 
 // tangent buffers for a batch of N directions, from a small most-recently-used cache (Jacobian assembly at N = 256
@@ -566,38 +543,15 @@ static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
     const Consts &c = ctx->c;
     const size_t P = c.P, G = c.G;
     w.N = N;
-    w.slab = x_use_slab();
-    size_t off = 0, stb = 0, stf = 0;
-    if (w.slab) {
-        // slab sweeps: a pass holds up to 8 groups x NW waves x DW directions
-        const size_t GM = (size_t)c.n_e * X.Sact * 64;
-        for (int n0 = 0; n0 < N;) {
-            XPass ps;
-            ps.n0 = n0;
-            w_plan(ctx, N - n0, ps.D, ps.NW);
-            ps.N = std::min(N - n0, XG * ps.D * ps.NW);
-            ps.groups = (ps.N + ps.D * ps.NW - 1) / (ps.D * ps.NW);
-            ps.dpol_off = off;
-            const size_t Wp = (size_t)ps.groups * ps.NW * ps.D;
-            off += P * Wp * G;
-            stb = std::max(stb, 2 * Wp * G);
-            stf = std::max(stf, 2 * Wp * GM);
-            w.Wmax = std::max(w.Wmax, (int)Wp);
-            w.passes.push_back(ps);
-            n0 += ps.N;
-        }
-    } else {
-        for (int n0 = 0; n0 < N; n0 += XG * X.dmax) {
-            XPass ps;
-            ps.n0 = n0; ps.N = std::min(N - n0, XG * X.dmax);
-            ps.D = 1; while (XG * ps.D < ps.N) ps.D *= 2;
-            ps.groups = (ps.N + ps.D - 1) / ps.D;
-            ps.dpol_off = off;
-            ps.NW = 0;
-            off += P * ps.groups * G * ps.D;
-            w.passes.push_back(ps);
-        }
-        w.Wmax = XG * X.dmax;
+    size_t off = 0;
+    for (int n0 = 0; n0 < N; n0 += XG * X.dmax) {
+        XPass ps;
+        ps.n0 = n0; ps.N = std::min(N - n0, XG * X.dmax);
+        ps.D = 1; while (XG * ps.D < ps.N) ps.D *= 2;
+        ps.groups = (ps.N + ps.D - 1) / ps.D;
+        ps.dpol_off = off;
+        off += P * ps.groups * G * ps.D;
+        w.passes.push_back(ps);
     }
     if ((int)w.passes.size() > XPASS_MAX) {
         const int np_ = (int)w.passes.size();
@@ -610,16 +564,15 @@ static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
         HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
         HIPC(ctx, dmalloc(&w.dxr, P * N)); HIPC(ctx, dmalloc(&w.dxw, P * N)); HIPC(ctx, dmalloc(&w.dxt, P * N));
         HIPC(ctx, dmalloc(&w.dpol, off));
-        const size_t W = (size_t)w.Wmax, nb = w.slab ? (size_t)X.Sact : (size_t)X.Sact * c.n_e;
+        const size_t W = (size_t)XG * X.dmax, nb = (size_t)X.Sact * c.n_e;
         HIPC(ctx, dmalloc(&w.daggpart, P * nb * W));
         HIPC(ctx, hipMemset(w.daggpart, 0, sizeof(double) * P * nb * W));
         HIPC(ctx, dmalloc(&w.dagg_pass, P * W));
         HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
-        if (w.slab) { HIPC(ctx, dmalloc(&w.st_b, stb)); HIPC(ctx, dmalloc(&w.st_f, stf)); }
         return HANK_OK;
     };
     const int rc = alloc();
-    if (rc) { x_free_tan(w); X.tans.pop_front(); return rc; }
+    if (rc) { x_free_tan(w); X.tans.pop_front(); (void)hipGetLastError(); return rc; }
     *out = &w;
     return HANK_OK;
 }
@@ -641,44 +594,6 @@ static void x_launch_tan(int D, bool back, dim3 grd, dim3 blk, size_t lds, hipSt
     else if (D == 2) XL(2);
     else if (D == 4) { if constexpr (MAXT == 768) XL(4); }
 #undef XL
-}
-
-// slab sweeps: DW x NEC instantiations (NEC = n_e rounded up to a multiple of 4: the lane's columns live in registers)
-template <int DW>
-static void w_launch_nec(int NEC, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const WTanBackArgs &ab, const WTanFwdArgs &af) {
-#define WL(NV)                                                                                       \
-    do {                                                                                             \
-        if (blk.x <= 256) {          /* one wave per SIMD: the whole register file */                \
-            if (back) hipLaunchKernelGGL((k_wtan_back<DW, NV, 256>), grd, blk, lds, s, ab);          \
-            else hipLaunchKernelGGL((k_wtan_fwd<DW, NV, 256>), grd, blk, lds, s, af);                \
-        } else {                                                                                     \
-            if (back) hipLaunchKernelGGL((k_wtan_back<DW, NV, 512>), grd, blk, lds, s, ab);          \
-            else hipLaunchKernelGGL((k_wtan_fwd<DW, NV, 512>), grd, blk, lds, s, af);                \
-        }                                                                                            \
-    } while (0)
-    if (NEC == 4) WL(4);
-    else if (NEC == 8) WL(8);
-    else if (NEC == 12) WL(12);
-    else WL(16);
-#undef WL
-}
-// version 3 of the backward slab sweep (rolled columns, no loader wave)
-template <int DW>
-static void v_launch_nec(int NEC, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const WTanBackArgs &ab) {
-    if (NEC == 4) hipLaunchKernelGGL((k_vtan_back<DW, 4, 512>), grd, blk, lds, s, ab);
-    else if (NEC == 8) hipLaunchKernelGGL((k_vtan_back<DW, 8, 512>), grd, blk, lds, s, ab);
-    else if (NEC == 12) hipLaunchKernelGGL((k_vtan_back<DW, 12, 512>), grd, blk, lds, s, ab);
-    else hipLaunchKernelGGL((k_vtan_back<DW, 16, 512>), grd, blk, lds, s, ab);
-}
-static void v_launch_back(int DW, int NEC, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const WTanBackArgs &ab) {
-    if (DW == 1) v_launch_nec<1>(NEC, grd, blk, lds, s, ab);
-    else if (DW == 2) v_launch_nec<2>(NEC, grd, blk, lds, s, ab);
-    else v_launch_nec<4>(NEC, grd, blk, lds, s, ab);
-}
-static void w_launch(int DW, int NEC, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const WTanBackArgs &ab, const WTanFwdArgs &af) {
-    if (DW == 1) w_launch_nec<1>(NEC, back, grd, blk, lds, s, ab, af);
-    else if (DW == 2) w_launch_nec<2>(NEC, back, grd, blk, lds, s, ab, af);
-    else w_launch_nec<4>(NEC, back, grd, blk, lds, s, ab, af);
 }
 
 static int x_serialize_begin(hank_ctx *ctx) {
@@ -767,59 +682,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     if (!X.src_valid) {      // once per recorded primal: which members each member's gathers read, period by period
         hipLaunchKernelGGL(k_xsrc_back, dim3((unsigned)P, X.Sact), dim3(256), 0, s, c, ctx->R, X.Sact, X.srcB);
         hipLaunchKernelGGL(k_xsrc_fwd, dim3((unsigned)P, X.Sact), dim3(256), 0, s, c, ctx->R, X.Sact, X.srcF);
-        const unsigned nr = (unsigned)((P * X.Sact + 255) / 256);
-        hipLaunchKernelGGL(k_wrdr, dim3(nr), dim3(256), 0, s, X.srcB, (int)P, X.Sact, X.rdrB);
-        hipLaunchKernelGGL(k_wrdr, dim3(nr), dim3(256), 0, s, X.srcF, (int)P, X.Sact, X.rdrF);
-        hipLaunchKernelGGL(k_wpub_back, dim3((unsigned)P), dim3(256), 0, s, c, ctx->R, X.Sact, X.pubB);
         X.src_valid = true;
-    }
-    if (w->slab) {
-        const char *ng = getenv("HANK_XNEIGH");      // dev knob: 0 = every period waits for every member
-        const bool neigh = !(ng && atoi(ng) == 0);
-        const int NEC = w_nec(ctx);
-        WTanBackArgs ab{};
-        ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st = w->st_b;
-        ab.src = neigh ? X.srcB : nullptr; ab.rdr = neigh ? X.rdrB : nullptr;
-        const char *ar = getenv("HANK_W_ALLROWS");   // dev knob: 1 = every row goes through L2 (no halo selection)
-        const bool allrows = ar && atoi(ar) != 0;
-        ab.pub = allrows ? nullptr : X.pubB;
-        WTanFwdArgs af{};
-        af.c = c; af.R = ctx->R; af.st = w->st_f; af.daggpart = w->daggpart;
-        af.src = neigh ? X.srcF : nullptr; af.rdr = neigh ? X.rdrF : nullptr; af.all_rows = allrows ? 1 : 0;
-        const dim3 grd(X.grid);
-        HIPC(ctx, hipEventRecord(ctx->ev[3], s));
-        for (int p = 0; p < np; p++) {
-            const XPass &ps = w->passes[p];
-            ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.NW = ps.NW; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
-            const char *v3 = getenv("HANK_W_V3");
-            if (v3 && atoi(v3) != 0) v_launch_back(ps.D, NEC, grd, dim3(64 * ps.NW), vback_lds(c.n_e, NEC, ps.D, ps.NW), s, ab);
-            else w_launch(ps.D, NEC, true, grd, dim3(64 * (ps.NW + 1)), wback_lds(c.n_e, NEC, ps.D, ps.NW), s, ab, af);
-        }
-        HIPC(ctx, hipEventRecord(ctx->ev[4], s));
-        HIPC(ctx, hipEventRecord(ctx->ev[7], s));
-        for (int p = 0; p < np; p++) {
-            const XPass &ps = w->passes[p];
-            const int W = ps.groups * ps.NW * ps.D;
-            af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.NW = ps.NW; af.N = ps.N; af.W = W; af.dpol = w->dpol + ps.dpol_off;
-            w_launch(ps.D, NEC, false, grd, dim3(64 * (ps.NW + 1)), wfwd_lds(c.n_e, NEC, ps.D, ps.NW), s, ab, af);
-            if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
-            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, X.Sact, W, w->dagg_pass);
-            hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, W, ps.n0, ps.N, w->dagg_cm);
-        }
-        HIPC(ctx, hipGetLastError());
-        rc = x_serialize_end(ctx);
-        if (rc) return rc;
-        ctx->stats[0] += 2 * np;
-        X.last_passes = 1 + np;
-        ctx->launches[2] = ctx->launches[3] = np;
-        ctx->ev_valid[2] = ctx->ev_valid[3] = true;
-        ctx->ev_valid[4] = ctx->ev_valid[5] = false;
-        for (XTan &t : X.tans) t.valid = false;
-        w->valid = true;
-        ctx->xcur = w;
-        ctx->last_tan = 1;
-        for (TanWork &t : ctx->tws) t.valid = false;
-        return HANK_OK;
     }
     const char *ng = getenv("HANK_XNEIGH");      // dev knob: 0 = every period waits for every member
     const bool neigh = !(ng && atoi(ng) == 0);
@@ -982,6 +845,7 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
             return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=xcd: n_a=%d needs %d workgroups per XCD (the device has %d) and %zu bytes of LDS per workgroup (it has %zu)", c.n_a,
                         (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG, std::max(x_lds_primal_back(c), x_lds_primal_fwd(c)), (size_t)prop.sharedMemPerBlock);
         ctx->schedule = 1;
+        ctx->forced_xcd = true;
     }
     if (const char *xm = getenv("HANK_XJVP_MAX")) ctx->xjvp_max = atoi(xm);
     int rc = HANK_OK;
@@ -1116,7 +980,6 @@ static bool use_x_primal(const hank_ctx *ctx) { return ctx->schedule >= 1; }
 // to the per-period launches, which take any T
 static bool x_tan_fits(const hank_ctx *ctx, int N) {
     const XWork &X = ctx->xw;
-    if (x_use_slab()) return true;        // (the slab sweeps size their waves to the LDS: w_plan)
     int D = 1;
     while (XG * D < N && D < X.dmax) D *= 2;
     return std::max(x_lds_tan_back(ctx->c, D), x_lds_tan_fwd(ctx->c, D)) <= (size_t)X.lds_max;
@@ -1132,10 +995,7 @@ static int to_launch_schedule(hank_ctx *ctx) {
     if (!ctx->g_pback) return build_primal_graphs(ctx);
     return HANK_OK;
 }
-static bool x_fallback_allowed() {
-    const char *se = getenv("HANK_SCHEDULE");
-    return !(se && strcmp(se, "xcd") == 0);      // a forced schedule fails loudly instead
-}
+static bool x_fallback_allowed(const hank_ctx *ctx) { return !ctx->forced_xcd; }      // a schedule forced at hank_create fails loudly instead
 
 int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
     ENTER(ctx);
@@ -1166,7 +1026,7 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
         rc = x_primal(ctx, xhh, hipMemcpyHostToDevice, nullptr);
         if (rc) return rc;
         rc = fetch_device_error(ctx);
-        if (rc == HANK_ERR_SWEEP && x_fallback_allowed()) rc = to_launch_schedule(ctx);
+        if (rc == HANK_ERR_SWEEP && x_fallback_allowed(ctx)) rc = to_launch_schedule(ctx);
         else if (rc) return rc;
         else done = true;
         if (rc) return rc;
@@ -1231,7 +1091,7 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
         rc = x_dual(ctx, nullptr, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
         if (rc) return rc;
         rc = fetch_device_error(ctx);
-        const bool fell_back = rc == HANK_ERR_SWEEP && x_fallback_allowed();
+        const bool fell_back = rc == HANK_ERR_SWEEP && x_fallback_allowed(ctx);
         if (fell_back) {
             rc = to_launch_schedule(ctx);
             if (rc) return rc;
@@ -1312,7 +1172,7 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
         rc = x_dual(ctx, xhh, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
         if (rc) return rc;
         rc = fetch_device_error(ctx);
-        if (rc == HANK_ERR_SWEEP && x_fallback_allowed()) rc = to_launch_schedule(ctx);
+        if (rc == HANK_ERR_SWEEP && x_fallback_allowed(ctx)) rc = to_launch_schedule(ctx);
         else if (rc) return rc;
         else d_dagg = ctx->xcur->dagg_cm;
         if (rc) return rc;
@@ -1469,10 +1329,6 @@ int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
         HIPC(ctx, dmalloc(&tmp, total));
         for (const XPass &ps : x->passes) {
             const size_t cnt = (size_t)ctx->c.P * ctx->c.G * ps.N;
-            if (ps.NW > 0)
-                hipLaunchKernelGGL(k_wexport_dpol, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, x->dpol + ps.dpol_off, ctx->c.G, ctx->c.P,
-                                   ps.groups * ps.NW, ps.D, ps.n0, ps.N, tmp);
-            else
             hipLaunchKernelGGL(k_xexport_dpol, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, x->dpol + ps.dpol_off, ctx->c.G, ctx->c.P,
                                ps.groups, ps.D, ps.n0, ps.N, tmp);
         }
@@ -1648,7 +1504,7 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
             return HANK_OK;
         }
         // the group did not form or a wait timed out: this context continues on the launches (a forced schedule fails loudly)
-        if (!x_fallback_allowed())
+        if (!x_fallback_allowed(ctx))
             return fail(ctx, HANK_ERR_SWEEP, "persistent value iteration: %s on XCD %u", hsy.status[0] == XERR_PLACEMENT ? "the group is short of members" : "a wait timed out", hsy.status[1]);
         rc = to_launch_schedule(ctx);
         if (rc) return rc;
@@ -1761,7 +1617,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
             ctx->errmsg[0] = 0;
             return HANK_OK;
         }
-        if (!x_fallback_allowed())
+        if (!x_fallback_allowed(ctx))
             return fail(ctx, HANK_ERR_SWEEP, "persistent power method: %s on XCD %u", hsy.status[0] == XERR_PLACEMENT ? "the group is short of members" : "a wait timed out", hsy.status[1]);
         rc = to_launch_schedule(ctx);
         if (rc) return rc;

@@ -31,8 +31,7 @@ struct Consts {
 struct Record {
     double *s, *kc, *A, *B, *u, *v, *pol, *lw, *ig, *Dseq;
     int *ib, *lo, *start, *clo;
-    int4 *seg;      // per target row: {start[r-1], start[r], start[r+1], lo[r]} — ONE read instead of three; .w = the row's own
-                    // lottery bracket as a SOURCE (-1: clamped at the first grid point), which tells the slab sweeps who reads it
+    int4 *seg;      // per target row: {start[r-1], start[r], start[r+1], -} — ONE read instead of three
     double2 *lwg;   // per source row: {lottery weight w, weight-tangent factor ig * D_{t-1}} — ONE 16-byte read per source in the forward tangent kernel
 };
 
@@ -380,7 +379,7 @@ __global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
     for (int r = threadIdx.x; r <= n; r += blockDim.x) st[r] = shst[r];
     // per target row: its three segment bounds in one 16-byte record
     for (int r = threadIdx.x; r < n; r += blockDim.x)
-        R.seg[base + r] = make_int4(r > 0 ? shst[r - 1] : shst[r], shst[r], shst[r + 1], shlo[r]);
+        R.seg[base + r] = make_int4(r > 0 ? shst[r - 1] : shst[r], shst[r], shst[r + 1], 0);
 }
 
 // ---- distribution push-forward, one period (ForwardIteration.jl:95-99, :297-308) -------------

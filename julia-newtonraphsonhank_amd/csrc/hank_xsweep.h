@@ -97,34 +97,28 @@ struct XRows {
         }
     }
 };
-// dev knob: how the policy partials — a pure stream — leave and enter the CU (0 plain, 1 nontemporal)
-#ifndef HANK_XDPOL_NT
-#define HANK_XDPOL_NT 0
-#endif
+// the policy partials are a pure stream: written once by the backward sweep, read once by the forward sweep. Stores are
+// nontemporal (the lines are not kept for a reader that comes a whole sweep later: backward sweep 1.36 -> 1.28 ms at
+// N = 32); loads stay plain — a row is one member's own row AND a source of its neighbours in the same period, and with
+// nontemporal loads the forward sweep took 3.46 ms instead of 2.25 (profiles/r03_col_nt_stream.log). L2 is write-through
+// either way: every stored byte reaches the fabric once (WRITE_SIZE = stream + state with both flavours).
 typedef double xv2d __attribute__((ext_vector_type(2)));
 template <int D>
-__device__ __forceinline__ void xstore_row(double *p, const double *v) {      // plain stores: the line stays in the XCD's L2
+__device__ __forceinline__ void xstore_row(double *p, const double *v) {
     if (D == 1) {
-        if (HANK_XDPOL_NT) __builtin_nontemporal_store(v[0], p);
-        else *p = v[0];
+        __builtin_nontemporal_store(v[0], p);
     } else {
 #pragma unroll
-        for (int k = 0; k < D / 2; k++) {
-            if (HANK_XDPOL_NT) { xv2d q; q.x = v[2 * k]; q.y = v[2 * k + 1]; __builtin_nontemporal_store(q, reinterpret_cast<xv2d *>(p) + k); }
-            else reinterpret_cast<double2 *>(p)[k] = make_double2(v[2 * k], v[2 * k + 1]);
-        }
+        for (int k = 0; k < D / 2; k++) { xv2d q; q.x = v[2 * k]; q.y = v[2 * k + 1]; __builtin_nontemporal_store(q, reinterpret_cast<xv2d *>(p) + k); }
     }
 }
 template <int D>
 __device__ __forceinline__ void xload_row_plain(const double *p, double *v) {  // read-only inputs (written by an earlier launch)
     if (D == 1) {
-        v[0] = HANK_XDPOL_NT ? __builtin_nontemporal_load(p) : *p;
+        v[0] = *p;
     } else {
 #pragma unroll
-        for (int k = 0; k < D / 2; k++) {
-            if (HANK_XDPOL_NT) { const xv2d q = __builtin_nontemporal_load(reinterpret_cast<const xv2d *>(p) + k); v[2 * k] = q.x; v[2 * k + 1] = q.y; }
-            else { const double2 q = reinterpret_cast<const double2 *>(p)[k]; v[2 * k] = q.x; v[2 * k + 1] = q.y; }
-        }
+        for (int k = 0; k < D / 2; k++) { const double2 q = reinterpret_cast<const double2 *>(p)[k]; v[2 * k] = q.x; v[2 * k + 1] = q.y; }
     }
 }
 

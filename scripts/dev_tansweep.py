@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""dev: the slab sweeps (csrc/hank_wsweep.h) against the column-wave persistent sweeps and the per-period launches:
-bitwise dpol, aggregates to rounding, and time per batch width.  usage: dev_wsweep.py [parity|time|all] [N ...]"""
+"""dev: the persistent tangent sweeps against the per-period launches at a recorded primal: bitwise dpol, aggregates to
+rounding, and time per batch width.  usage: dev_tansweep.py [parity|time] [N ...]"""
 import os
 import sys
 import time
@@ -107,50 +107,11 @@ def timing(n_a, n_e, T, Ns, envs=({},), reps=None):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    SL, COL = {"HANK_XTAN": "slab"}, {"HANK_XTAN": "col"}
-    if what in ("all", "parity"):
-        parity(50, 2, 100, 3, envs=(SL,))
-        parity(37, 3, 9, 5, envs=(SL,))
-        parity(130, 3, 20, 9, envs=(SL, dict(SL, HANK_W_DW=1, HANK_W_NW=2), dict(SL, HANK_W_DW=4, HANK_W_NW=1)))
-        parity(200, 7, 40, 32, envs=(SL, dict(SL, HANK_W_DW=4, HANK_W_NW=1), dict(SL, HANK_W_DW=1, HANK_W_NW=4)))
-        parity(40, 16, 8, 6, envs=(SL,))
-        parity(37, 3, 9, 70, envs=(SL,))
-        parity(500, 4, 300, 40, shock=0.01, envs=(SL,))
-        parity(2000, 11, 300, 32, shock=0.01, envs=(SL,))
-        parity(2000, 11, 300, 128, shock=0.01, envs=(SL, dict(SL, HANK_W_DW=2, HANK_W_NW=7), dict(SL, HANK_W_DW=4, HANK_W_NW=3), dict(SL, HANK_W_ALLROWS=1)))
-    if what in ("all", "time"):
-        Ns = [int(v) for v in sys.argv[2:]] or [1, 8, 16, 32, 64, 128, 256]
-        timing(2000, 11, 300, Ns, envs=(SL, COL, {"SCHED": "launch"}))
-    if what == "col":
-        timing(2000, 11, 300, [int(v) for v in sys.argv[2:]] or [32], envs=(COL,), reps=5)
-    if what == "slab":
-        timing(2000, 11, 300, [int(v) for v in sys.argv[2:]] or [256], envs=(SL,), reps=3)
-    if what == "v3":
-        V3 = dict(SL, HANK_W_V3=1)
-        parity(130, 3, 20, 9, envs=(V3, dict(V3, HANK_W_DW=1, HANK_W_NW=2), dict(V3, HANK_W_DW=4, HANK_W_NW=1)))
-        parity(200, 7, 40, 32, envs=(V3, dict(V3, HANK_W_DW=4, HANK_W_NW=1)))
-        parity(40, 16, 8, 6, envs=(V3,))
-        parity(37, 3, 9, 70, envs=(V3,))
-        parity(2000, 11, 300, 128, shock=0.01, envs=(V3, dict(V3, HANK_W_DW=2, HANK_W_NW=7), dict(V3, HANK_W_DW=4, HANK_W_NW=6), dict(V3, HANK_W_ALLROWS=1)))
-        def E(dw, nw, **kw):
-            return dict(V3, HANK_W_DW=dw, HANK_W_NW=nw, **kw)
-        timing(2000, 11, 300, [1], envs=(E(1, 1),))
-        timing(2000, 11, 300, [32], envs=(E(4, 1), E(2, 2), E(1, 4)))
-        timing(2000, 11, 300, [128], envs=(E(4, 4), E(2, 7), E(2, 8)))
-        timing(2000, 11, 300, [192], envs=(E(4, 6), E(4, 5)))
-        timing(2000, 11, 300, [256], envs=(E(4, 4), E(4, 6), E(2, 8)))
-    if what == "v3t":
-        V3 = dict(SL, HANK_W_V3=1)
-        def E(dw, nw, **kw):
-            return dict(V3, HANK_W_DW=dw, HANK_W_NW=nw, **kw)
-        timing(2000, 11, 300, [1], envs=(E(1, 1),))
-        timing(2000, 11, 300, [32], envs=(E(2, 2),))
-        timing(2000, 11, 300, [128], envs=(E(4, 4), E(2, 7)))
-    if what == "tune":
-        def E(dw, nw, **kw):
-            return dict(SL, HANK_W_DW=dw, HANK_W_NW=nw, **kw)
-        timing(2000, 11, 300, [32], envs=(E(4, 1), E(2, 2), E(1, 4), E(2, 2, HANK_W_ALLROWS=1)))
-        timing(2000, 11, 300, [128], envs=(E(4, 4), E(4, 3), E(2, 7), E(2, 4), E(4, 4, HANK_W_ALLROWS=1)))
-        timing(2000, 11, 300, [256], envs=(E(4, 4), E(4, 3), E(2, 7)))
-        timing(2000, 11, 300, [1, 8, 16, 64], envs=(SL,))
+    what = sys.argv[1] if len(sys.argv) > 1 else "time"
+    Ns = [int(v) for v in sys.argv[2:]] or [1, 8, 16, 32, 64, 128, 256]
+    if what == "time":        # hank_jvp at a recorded primal: the persistent sweeps forced on every width, then the launches
+        timing(2000, 11, 300, Ns, envs=({}, {"SCHED": "launch"}))
+    if what == "parity":      # dpol of the persistent sweeps bit for bit against the launches
+        for shape in ((50, 2, 100, 3), (37, 3, 9, 5), (130, 3, 20, 9), (200, 7, 40, 32), (40, 16, 8, 6), (37, 3, 9, 70), (500, 4, 300, 40)):
+            parity(*shape)
+        parity(2000, 11, 300, 32, shock=0.01)

@@ -46,7 +46,8 @@ def test_host_entries_fall_back_to_the_launches(hank, monkeypatch, fault):
     # hank_jvp: the primal sweeps run, the tangent sweeps are faulted — the launches re-record the primal and serve the batch
     hb = _block(hank, m, monkeypatch, fault=fault + ":tangent")
     hb.set_boundary(ss.value, ss.D)
-    assert np.array_equal(hb.primal(x[2:4]), agg0) and hb.stats()["fallbacks"] == 0
+    a_x = hb.primal(x[2:4])         # (persistent Float64 sweeps: the aggregate's partial sums combine in another order than the launches')
+    assert np.max(np.abs(a_x - agg0)) <= 1e-13 * np.abs(agg0).max() and hb.stats()["fallbacks"] == 0
     assert np.array_equal(hb.jvp(y), d0)
     assert hb.stats()["fallbacks"] == 1 and hb.stats()["schedule"] == 0
     hb.close()

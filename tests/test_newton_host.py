@@ -56,6 +56,10 @@ def test_julia_shim_uses_constructors_the_reference_has():
     assert body.count("_run_block!") == 1 and "ss_initial === nothing || _run_block!" in body
     fwd = code[code.index("function ForwardIteration("):]
     assert "_run_block!(seqs, D0)" in fwd
+    # one context per (model, HIP device): hank_create_on when a device is named, and the column shard helper drives them from tasks
+    assert "hank_context(model::SequenceModel; device" in code and "(:hank_create_on, LIBHANK)" in code
+    shard = code[code.index("function sharded_jvp_columns("):]
+    assert "Threads.@spawn" in shard and "hank_context(model; device = dev)" in shard and "(:hank_primal_jvp, LIBHANK)" in shard
     # every ccall target is a symbol the C ABI exports
     from hank_amd.hip import ABI_SYMBOLS
     for sym in set(re.findall(r"ccall\(\(:(\w+), LIBHANK\)", src)):
