@@ -30,7 +30,7 @@ def build(n_a=1000, n_e=7, T=500):
     return m, ss
 
 
-def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False):
+def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False, inner="fixed_point", jacobian="toeplitz"):
     import hank_amd as h
     import hank_amd.parallel  # noqa: F401  (pulls in torch before the clock starts)
     t0 = time.perf_counter()
@@ -41,11 +41,11 @@ def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False
     keys = h.vars_of_type(m, "endogenous")
     x0 = np.tile(np.array([ss.vars[k] for k in keys]), P)
     t0 = time.perf_counter()
-    J = h.getSteadyStateJacobian(ss, m)
+    J = h.getSteadyStateJacobian(ss, m, method=jacobian)
     t_jac = time.perf_counter() - t0
     h.y_Iteration.total_jvps = 0
     t0 = time.perf_counter()
-    x = h.NewtonRaphsonHANK(x0, J, {"ei": ei}, m, ss, ss, ε=eps, verbose=verbose)
+    x = h.NewtonRaphsonHANK(x0, J, {"ei": ei}, m, ss, ss, ε=eps, verbose=verbose, inner=inner)
     t_newton = time.perf_counter() - t0
     lin = h.LinearizedFunction(x, {"ei": ei}, m, ss, ss)
     X = x.reshape(len(keys), P, order="F")
@@ -53,7 +53,7 @@ def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False
            "B": m.params.B, "calibrate_and_steady_state_s": round(t_ss, 3), "ss_jacobian_s": round(t_jac, 3),
            "newton_s": round(t_newton, 3), "newton_iterations": h.NewtonRaphsonHANK.iterations,
            "jvps": h.y_Iteration.total_jvps, "residual_norm": float(np.linalg.norm(lin.Fx)),
-           "wall_to_converged_path_s": round(t_jac + t_newton, 3),
+           "wall_to_converged_path_s": round(t_jac + t_newton, 3), "inner": inner, "jacobian": jacobian,
            "impact": {k: float(X[j, 0] - ss.vars[k]) for j, k in enumerate(keys)}}
     return out, x, m, ss
 
@@ -65,6 +65,8 @@ if __name__ == "__main__":
     ap.add_argument("--T", type=int, default=500)
     ap.add_argument("--shock", type=float, default=0.0025)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--inner", default="fixed_point", choices=["fixed_point", "krylov"])
+    ap.add_argument("--jacobian", default="toeplitz", choices=["toeplitz", "columns"])
     a = ap.parse_args()
     import os
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -74,7 +76,7 @@ if __name__ == "__main__":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
-    out = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose and rank == 0)[0]
+    out = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose and rank == 0, inner=a.inner, jacobian=a.jacobian)[0]
     out["n_gpus"] = world
     if rank == 0:
         print(json.dumps(out))
