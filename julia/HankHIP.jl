@@ -173,3 +173,30 @@ function sharded_jvp_columns(model::SequenceModel, ss_end, ss_initial, xhh::Matr
     end
     return dagg
 end
+
+# ---- the household block of getSteadyStateJacobian (SteadyStateJacobian.jl:187-256, :293-323, :358-387) ------------------------
+# JBI (n_endog forward-mode JVPs through BackwardIteration seeded at the last period, :240-243), JFI (Zygote pullbacks
+# through ForwardIteration, :249-253) and helper = JFI * JBI (:300-305) collapse into ONE call: hank_fake_news returns the
+# fake-news matrix F[u, j, k] and the direct term Dv[j, k] of the household block at the steady state; the Toeplitz
+# recursion (:363-371) stays here. Returns J[t, s, k] = d agg_t / d xhh_{k,s} (xhh rows in the order of `ctx.hh_rows`);
+# the caller places it behind the equations' direct blocks (:124-145) exactly where `helper` goes today.
+function household_jacobian_toeplitz(model::SequenceModel, ss; device = nothing)
+    ctx = hank_context(model; device = device)
+    P = ctx.P; n_hh = length(ctx.hh_rows)
+    xhh = Float64[ss.vars[k] for k in ctx.hh_rows, _ in 1:P]                      # the constant steady-state path (:53-57)
+    _check(ctx.ptr, ccall((:hank_set_boundary, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr,
+                          Matrix{Float64}(ss.value), Vector{Float64}(ss.D)))
+    agg = Vector{Float64}(undef, P)
+    _check(ctx.ptr, ccall((:hank_primal, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, xhh, agg))
+    F = Array{Float64}(undef, P, P, n_hh); Dv = Matrix{Float64}(undef, P, n_hh)
+    _check(ctx.ptr, ccall((:hank_fake_news, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, F, Dv))
+    J = similar(F)
+    for k in 1:n_hh
+        J[1, :, k] = Dv[:, k] .+ F[1, :, k]
+        for t in 2:P
+            J[t, 1, k] = F[t, 1, k]
+            J[t, 2:P, k] = J[t-1, 1:P-1, k] .+ F[t, 2:P, k]
+        end
+    end
+    return J
+end

@@ -60,6 +60,9 @@ def test_julia_shim_uses_constructors_the_reference_has():
     assert "hank_context(model::SequenceModel; device" in code and "(:hank_create_on, LIBHANK)" in code
     shard = code[code.index("function sharded_jvp_columns("):]
     assert "Threads.@spawn" in shard and "hank_context(model; device = dev)" in shard and "(:hank_primal_jvp, LIBHANK)" in shard
+    # the household block of getSteadyStateJacobian: one hank_fake_news + the reference's recursion (SteadyStateJacobian.jl:363-371)
+    toe = code[code.index("function household_jacobian_toeplitz("):]
+    assert "(:hank_fake_news, LIBHANK)" in toe and "J[t-1, 1:P-1, k] .+ F[t, 2:P, k]" in toe and "Dv[:, k] .+ F[1, :, k]" in toe
     # every ccall target is a symbol the C ABI exports
     from hank_amd.hip import ABI_SYMBOLS
     for sym in set(re.findall(r"ccall\(\(:(\w+), LIBHANK\)", src)):
