@@ -219,7 +219,7 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     return extra
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -228,8 +228,195 @@ def main():
     ap.add_argument("--tangents", type=int, default=None, help="override the per-GPU tangent batch width")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--split", action="store_true", help="hank_primal + hank_jvp as two calls instead of the dual-sweep hank_primal_jvp")
-    args = ap.parse_args()
+    ap.add_argument("--split", action="store_true", help="hank_primal + hank_jvp as two calls instead of the dual pass hank_primal_jvp")
+    ap.add_argument("--mode", default="ranks", choices=("ranks", "devicegroup"),
+                    help="ranks: one process per GPU + one RCCL all-gather per step (the driver's contract); "
+                         "devicegroup: ONE process, one context per GPU (hank_create_on), no collective")
+    ap.add_argument("--stand-in", action="store_true",
+                    help="CPU test of the launcher and of the distributed plumbing: gloo, a stand-in step, no GPU, no product code")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N fresh ranks — one process per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would give them —
+    BEFORE this process has made any GPU call (it never makes one), relay rank 0's JSON line, and fail if any rank fails.
+    Children are started, never exec'ed into: no process that has touched a GPU is replaced."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env, cwd=str(ROOT),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # a rank that dies leaves the others in a collective: watch all of them, end the rest when one fails
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+                break
+        if procs[0].poll() is None or failed is None:
+            time.sleep(0.05)
+        if failed is None and all(p.poll() is not None for p in procs):
+            break
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode not in (None, 0):
+                failed = (r, p.returncode)
+                break
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:      # noqa: BLE001
+                p.kill()
+        print(f"bench.py: rank {failed[0]} of {args.gpus} exited with status {failed[1]}", file=sys.stderr)
+        return 1
+    out = procs[0].stdout.read()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if not lines:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def stand_in_main(args):
+    """the launcher / rendezvous / barrier / max-over-ranks / all-gather plumbing of main() on CPU tensors over gloo with a
+    stand-in step (tests/test_bench_launcher.py). Nothing of the product runs and nothing here is a measurement."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("BENCH_STANDIN_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    if use_dist:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_seen = dist.get_world_size() if use_dist else 1
+    if n_seen != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {n_seen} rank(s)")
+    P, N = 7, 4
+    local = torch.full((P * N,), float(rank + 1), dtype=torch.float64)
+    every = torch.empty(world * P * N, dtype=torch.float64) if use_dist else None
+
+    def step():
+        local.mul_(1.0)
+        if use_dist:
+            dist.all_gather_into_tensor(every, local)
+
+    for _ in range(args.warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if use_dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        assert [float(every[r * P * N]) for r in range(world)] == [float(r + 1) for r in range(world)]
+    if rank == 0:
+        print(json.dumps({"metric": "stand-in (launcher test, not a measurement)", "value": world * N * args.steps / el, "unit": "JVPs/s",
+                          "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stand-in",
+                          "config": {"workload": "stand-in", "parallelism": f"tangent-sharded x{world}", "backend": "gloo"}}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def devicegroup_main(args):
+    """--mode devicegroup: ONE process drives one context per GPU (hank_create_on; the form a single-process host such as
+    the Julia reference uses). Every GPU runs the dual pass on its own 32 tangent columns
+    through the asynchronous _dev entries; the results stay in each GPU's HBM — no collective."""
+    import torch
+    import hank_amd as h
+    from conftest import ks_paths
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    ndev = torch.cuda.device_count()
+    if args.gpus > ndev:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process sees {ndev} GPU(s)")
+    wl = dict(WORKLOADS[args.workload])
+    if args.tangents:
+        wl["N"] = args.tangents
+    n_a, n_e, T, N = wl["n_a"], wl["n_e"], wl["T"], wl["N"]
+    P = T - 1
+    m, ss = load_or_solve_ss(n_a, n_e, T)
+    x, _ = ks_paths(m, ss, "x1", 0.01)
+    xf = np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()
+    first = h.household_block(m, device=0)
+    first.set_boundary(ss.value, ss.D)
+    blocks = [first] + [first.clone(device=d) for d in range(1, args.gpus)]
+    bufs = []
+    for d, hb in enumerate(blocks):
+        dev = torch.device("cuda", d)
+        rng = np.random.default_rng(1000 + d)
+        st = torch.cuda.Stream(device=dev)
+        hb.set_stream(st.cuda_stream)
+        bufs.append((torch.from_numpy(xf).to(dev), torch.from_numpy(rng.standard_normal(2 * P * N)).to(dev),
+                     torch.empty(P, dtype=torch.float64, device=dev), torch.empty(P * N, dtype=torch.float64, device=dev), st))
+
+    def step():
+        for hb, (dx_, dy_, ag_, out_, _) in zip(blocks, bufs):
+            hb.primal_jvp_dev(dx_.data_ptr(), dy_.data_ptr(), N, ag_.data_ptr(), out_.data_ptr())
+
+    def fence():
+        for hb in blocks:
+            hb.sync()
+
+    for _ in range(args.warmup):
+        step()
+    for hb in blocks:
+        hb.check()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    for hb in blocks:
+        hb.check()
+    out = {"metric": "sequence-space JVPs/sec (household block: BackwardIteration+ForwardIteration+aggregation, Krusell-Smith T=300)",
+           "value": args.gpus * N * args.steps / el, "unit": "JVPs/s", "n_gpus": len(blocks), "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": args.workload, "grid": f"{n_a}x{n_e}", "T": T, "tangents_per_gpu": N,
+                      "step": "1 dual pass per GPU: primal + N tangents (hank_primal_jvp_dev), no collective",
+                      "parallelism": f"one process, one context per GPU (hank_create_on) x{len(blocks)}"}}
+    print(json.dumps(out), flush=True)
+    for hb in blocks[1:]:
+        hb.close()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    launcher_env = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.mode == "ranks" and args.gpus > 1 and not launcher_env:
+        raise SystemExit(self_launch(args, argv))        # before anything here touches a GPU
+    if args.stand_in:
+        return stand_in_main(args)
+    if args.mode == "devicegroup":
+        return devicegroup_main(args)
 
     import torch
     import torch.distributed as dist
@@ -247,7 +434,10 @@ def main():
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    n_seen = dist.get_world_size() if use_dist else 1     # the ranks RCCL actually has
+    if n_seen != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {n_seen} rank(s): run `python bench.py --gpus N` "
+                         "(it starts its own ranks) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
 
     wl = dict(WORKLOADS[args.workload])
     if args.tangents:
@@ -359,7 +549,7 @@ def main():
         b_alg_batch = 2 * P * G * 8 * (1 + N)
         out = {
             "metric": "sequence-space JVPs/sec (household block: BackwardIteration+ForwardIteration+aggregation, Krusell-Smith T=300)",
-            "value": total_jvps / el, "unit": "JVPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total_jvps / el, "unit": "JVPs/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "grid": f"{n_a}x{n_e}", "T": T, "tangents_per_gpu": N,

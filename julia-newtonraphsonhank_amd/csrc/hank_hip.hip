@@ -77,6 +77,11 @@ struct XWork {
     double *st_s = nullptr, *st_ds = nullptr, *st_D = nullptr, *st_dD = nullptr;
     double *Dvirt = nullptr, *aggpart = nullptr, *rho = nullptr;
     int *srcB = nullptr, *srcF = nullptr;     // [P][Sact] source-member ranges of the tangent sweeps at the recorded primal
+    int2 *unitsF = nullptr;                   // [P][Sact][XUCAP] the forward sweeps' work units (k_xunits_fwd)
+    int *unit_overflow = nullptr;             // set by k_xunits_fwd when a member has more units than XUCAP
+    bool rng_valid = false;                   // srcF / unitsF belong to the recorded lottery
+    bool neigh = true;                        // dev knob HANK_XNEIGH=0 (read once, at hank_create): every period waits for every member
+    bool syncwave = true;                     // dev knob HANK_XSYNCWAVE=0 (read once, at hank_create): wave 0 polls instead of an extra wave
     int lds_max = 65536;
     int fault_where = 7;
     int fault = 0;                            // dev knob HANK_XFAULT=placement: every persistent launch finds its status word set ("a
@@ -455,13 +460,13 @@ static hipEvent_t g_xlast[64] = {};
 
 // dynamic LDS of the persistent kernels (the expressions the kernels carve up): it grows with the horizon P
 static size_t x_lds_primal_back(const Consts &c) { return sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * (size_t)c.P) + 64; }
-static size_t x_lds_primal_fwd(const Consts &c) { return sizeof(double) * ((size_t)c.n_e * 64) + sizeof(int) * (size_t)c.P * c.n_e + 64; }
 static size_t x_lds_tan_back(const Consts &c, int D) {
     const int SLt = D == 4 ? 6 : D;      // XTileT<D>::SL
     return sizeof(double) * ((size_t)SLt * c.n_e * 64 + c.P + 1 + 3 * (size_t)c.P * D) + sizeof(int) * (size_t)c.P + 64;
 }
-static size_t x_lds_tan_fwd(const Consts &c, int D) {
-    const int SLt = D == 4 ? 6 : D;
+// k_xfwd with NSL live slots (the D partials + the value): tile, Pi, {source range, clamped prefix} and source members of every period
+static size_t x_lds_fwd(const Consts &c, int NSL) {
+    const int SLt = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);      // XSlots<NSL>::SL
     return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * ((size_t)c.P * c.n_e + c.P) + 64;
 }
 // the grid fits the XCD-local schedule: a 63-row slab per CU of an XCD, and the Float64 sweeps' LDS (which holds the
@@ -469,7 +474,7 @@ static size_t x_lds_tan_fwd(const Consts &c, int D) {
 static bool x_supported(const hank_ctx *ctx, int cus, size_t lds_max) {
     const Consts &c = ctx->c;
     const int Sact = (c.n_a + XRW - 1) / XRW;
-    return cus >= XG && Sact <= cus / XG && c.n_e <= 16 && std::max(x_lds_primal_back(c), x_lds_primal_fwd(c)) <= lds_max;
+    return cus >= XG && Sact <= cus / XG && c.n_e <= 16 && std::max(x_lds_primal_back(c), x_lds_fwd(c, 1)) <= lds_max;
 }
 
 static void x_free_tan(XTan &w) {
@@ -484,7 +489,7 @@ static void x_free(hank_ctx *ctx) {
     X.tans.clear();
     ctx->xcur = nullptr;
     (void)hipFree(X.sync); (void)hipFree(X.st_s); (void)hipFree(X.st_ds); (void)hipFree(X.st_D); (void)hipFree(X.st_dD);
-    (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart); (void)hipFree(X.rho); (void)hipFree(X.srcB); (void)hipFree(X.srcF);
+    (void)hipFree(X.Dvirt); (void)hipFree(X.aggpart); (void)hipFree(X.rho); (void)hipFree(X.srcB); (void)hipFree(X.srcF); (void)hipFree(X.unitsF); (void)hipFree(X.unit_overflow);
     X = XWork();
 }
 
@@ -504,14 +509,19 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, hipMemset(X.sync, 0, sizeof(XSync) * ((size_t)2 + 2 * XPASS_MAX)));      // x_status reads blocks 0, 1 also when the launches recorded the primal
     HIPC(ctx, dmalloc(&X.st_s, 2 * XG * G));
     HIPC(ctx, dmalloc(&X.st_ds, 2 * XG * G * X.dmax));
-    HIPC(ctx, dmalloc(&X.st_D, 2 * XG * GV));
-    const size_t GM = (size_t)c.n_e * X.Sact * 64;       // member-major state of the tangent forward sweep: [n_e][members][64]
-    HIPC(ctx, dmalloc(&X.st_dD, 2 * XG * GM * X.dmax));
+    const size_t GM = (size_t)c.n_e * X.Sact * 64;       // member-major state of the forward sweeps: [n_e][members][64]
+    HIPC(ctx, dmalloc(&X.st_D, 2 * XG * std::max(GV, GM)));
+    HIPC(ctx, dmalloc(&X.st_dD, 2 * XG * GM * (X.dmax + 2)));      // D partials + the value, padded to pairs
     HIPC(ctx, dmalloc(&X.Dvirt, P * c.n_e * 64));
     HIPC(ctx, dmalloc(&X.aggpart, P * (size_t)X.Sact * c.n_e));
     HIPC(ctx, dmalloc(&X.rho, P));
     HIPC(ctx, dmalloc(&X.srcB, P * X.Sact));
     HIPC(ctx, dmalloc(&X.srcF, P * X.Sact));
+    HIPC(ctx, dmalloc(&X.unitsF, P * X.Sact * XUCAP));
+    HIPC(ctx, dmalloc(&X.unit_overflow, 1));
+    HIPC(ctx, hipMemset(X.unit_overflow, 0, sizeof(int)));
+    if (const char *ng = getenv("HANK_XNEIGH")) X.neigh = atoi(ng) != 0;
+    if (const char *sv = getenv("HANK_XSYNCWAVE")) X.syncwave = atoi(sv) != 0;
     X.lds_max = (int)prop.sharedMemPerBlock;
     if (const char *xf = getenv("HANK_XFAULT")) {      // "placement" | "timeout", optionally ":primal" | ":tangent" | ":fixedpoint" (default: every persistent launch)
         X.fault = strncmp(xf, "placement", 9) == 0 ? XERR_PLACEMENT : (strncmp(xf, "timeout", 7) == 0 ? XERR_TIMEOUT : 0);
@@ -579,21 +589,32 @@ static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
 
 
 template <int MAXT>
-static void x_launch_primal(bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XBackArgs &ab, const XFwdArgs &af) {
-    if (back) hipLaunchKernelGGL((k_xprimal_back<MAXT>), grd, blk, lds, s, ab);
-    else hipLaunchKernelGGL((k_xprimal_fwd<MAXT>), grd, blk, lds, s, af);
+static void x_launch_tan_back(int D, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XTanBackArgs &ab) {
+    if (D == 1) hipLaunchKernelGGL((k_xtan_back<1, MAXT>), grd, blk, lds, s, ab);
+    else if (D == 2) hipLaunchKernelGGL((k_xtan_back<2, MAXT>), grd, blk, lds, s, ab);
+    else if (D == 4) { if constexpr (MAXT == 768) hipLaunchKernelGGL((k_xtan_back<4, MAXT>), grd, blk, lds, s, ab); }
 }
+
+// k_xfwd<D, VAL>: D = 0 (the Float64 sweep alone, VAL), 1, 2, 4
 template <int MAXT>
-static void x_launch_tan(int D, bool back, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XTanBackArgs &ab, const XTanFwdArgs &af) {
-#define XL(DV)                                                                                       \
-    do {                                                                                             \
-        if (back) hipLaunchKernelGGL((k_xtan_back<DV, MAXT>), grd, blk, lds, s, ab);                 \
-        else hipLaunchKernelGGL((k_xtan_fwd<DV, MAXT>), grd, blk, lds, s, af);                       \
-    } while (0)
-    if (D == 1) XL(1);
-    else if (D == 2) XL(2);
-    else if (D == 4) { if constexpr (MAXT == 768) XL(4); }
-#undef XL
+static void x_launch_fwd(int D, bool val, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XSweepFwdArgs &a) {
+#define XF(DV, VV) hipLaunchKernelGGL((k_xfwd<DV, VV, MAXT>), grd, blk, lds, s, a)
+    if (D == 0) XF(0, true);
+    else if (D == 1) { if (val) XF(1, true); else XF(1, false); }
+    else if (D == 2) { if (val) XF(2, true); else XF(2, false); }
+    else if (D == 4) { if constexpr (MAXT == 768) { if (val) XF(4, true); else XF(4, false); } }
+#undef XF
+}
+static void x_launch_fwd(const XWork &X, int D, bool val, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XSweepFwdArgs &a) {
+    if (X.maxt == 768) x_launch_fwd<768>(D, val, grd, blk, lds, s, a);
+    else x_launch_fwd<1024>(D, val, grd, blk, lds, s, a);
+}
+// the forward sweeps' geometry at the recorded lottery (once per primal)
+static void x_ensure_rng(hank_ctx *ctx) {
+    XWork &X = ctx->xw;
+    if (X.rng_valid) return;
+    hipLaunchKernelGGL(k_xunits_fwd, dim3((unsigned)ctx->c.P, (unsigned)X.Sact), dim3(64), 0, ctx->stream, ctx->c, ctx->R, X.Sact, X.srcF, X.unitsF, X.unit_overflow);
+    X.rng_valid = true;
 }
 
 static int x_serialize_begin(hank_ctx *ctx) {
@@ -630,23 +651,26 @@ static int x_run_primal(hank_ctx *ctx) {
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
     // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
-    const char *swv = getenv("HANK_XSYNCWAVE");
-    const bool fits = 64 * (c.n_e + 1) <= X.maxt && !(swv && atoi(swv) == 0);
+    const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
     const dim3 grd(X.grid), blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkf = blk;
     XBackArgs ab{};
     ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.rho = X.rho; ab.sy = X.sync; ab.st_s = X.st_s;
     ab.err = ctx->d_err; ab.R = ctx->R;
-    XFwdArgs af{};
-    af.c = c; af.R = ctx->R; af.D0 = ctx->d_ss_D; af.sy = X.sync + 1; af.st_D = X.st_D; af.Dvirt = X.Dvirt; af.aggpart = X.aggpart;
-    const size_t ldsb = x_lds_primal_back(c), ldsf = x_lds_primal_fwd(c);
+    const size_t ldsb = x_lds_primal_back(c);
     HIPC(ctx, hipEventRecord(ctx->ev[0], s));
-    if (X.maxt == 768) x_launch_primal<768>(true, grd, blk, ldsb, s, ab, af);
-    else x_launch_primal<1024>(true, grd, blk, ldsb, s, ab, af);
+    if (X.maxt == 768) hipLaunchKernelGGL((k_xprimal_back<768>), grd, blk, ldsb, s, ab);
+    else hipLaunchKernelGGL((k_xprimal_back<1024>), grd, blk, ldsb, s, ab);
     HIPC(ctx, hipEventRecord(ctx->ev[1], s));
     hipLaunchKernelGGL(k_lottery, dim3((unsigned)(P * c.n_e)), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
+    X.rng_valid = false;
+    x_ensure_rng(ctx);
     HIPC(ctx, hipEventRecord(ctx->ev[6], s));
-    if (X.maxt == 768) x_launch_primal<768>(false, grd, blkf, ldsf, s, ab, af);
-    else x_launch_primal<1024>(false, grd, blkf, ldsf, s, ab, af);
+    {
+        XSweepFwdArgs fa{};
+        fa.c = c; fa.R = ctx->R; fa.sy = X.sync + 1; fa.st = X.st_D; fa.D0 = ctx->d_ss_D; fa.groups = 1; fa.Dvirt = X.Dvirt; fa.aggpart = X.aggpart;
+        fa.src = X.srcF; fa.units = X.unitsF; fa.all_members = X.neigh ? 0 : 1;
+        x_launch_fwd(X, 0, true, grd, blkf, x_lds_fwd(c, 1), s, fa);
+    }
     HIPC(ctx, hipEventRecord(ctx->ev[2], s));
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact * c.n_e, 1, ctx->d_agg);
     hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
@@ -681,38 +705,34 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);     // (the primal may have been recorded by the launches)
     if (!X.src_valid) {      // once per recorded primal: which members each member's gathers read, period by period
         hipLaunchKernelGGL(k_xsrc_back, dim3((unsigned)P, X.Sact), dim3(256), 0, s, c, ctx->R, X.Sact, X.srcB);
-        hipLaunchKernelGGL(k_xsrc_fwd, dim3((unsigned)P, X.Sact), dim3(256), 0, s, c, ctx->R, X.Sact, X.srcF);
         X.src_valid = true;
     }
-    const char *ng = getenv("HANK_XNEIGH");      // dev knob: 0 = every period waits for every member
-    const bool neigh = !(ng && atoi(ng) == 0);
+    x_ensure_rng(ctx);
+    const bool neigh = X.neigh;
     const dim3 grd(X.grid);
     // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
-    const char *swv = getenv("HANK_XSYNCWAVE");
-    const bool fits = 64 * (c.n_e + 1) <= X.maxt && !(swv && atoi(swv) == 0);
+    const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
     const dim3 blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkF = blk;
     XTanBackArgs ab{};
     ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st_ds = X.st_ds;
     ab.src = neigh ? X.srcB : nullptr;
-    XTanFwdArgs af{};
-    af.c = c; af.R = ctx->R; af.st_dD = X.st_dD; af.Dvirt = X.Dvirt; af.daggpart = w->daggpart; af.src = neigh ? X.srcF : nullptr;
+    XSweepFwdArgs fa{};
+    fa.c = c; fa.R = ctx->R; fa.st = X.st_dD; fa.daggpart = w->daggpart; fa.src = X.srcF; fa.units = X.unitsF; fa.all_members = neigh ? 0 : 1;
     HIPC(ctx, hipEventRecord(ctx->ev[3], s));
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
         const size_t lds = x_lds_tan_back(c, ps.D);
-        if (X.maxt == 768) x_launch_tan<768>(ps.D, true, grd, blk, lds, s, ab, af);
-        else x_launch_tan<1024>(ps.D, true, grd, blk, lds, s, ab, af);
+        if (X.maxt == 768) x_launch_tan_back<768>(ps.D, grd, blk, lds, s, ab);
+        else x_launch_tan_back<1024>(ps.D, grd, blk, lds, s, ab);
     }
     HIPC(ctx, hipEventRecord(ctx->ev[4], s));
     HIPC(ctx, hipEventRecord(ctx->ev[7], s));
     const int nb = X.Sact * c.n_e;
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
-        af.sy = X.sync + 2 + 2 * p + 1; af.groups = ps.groups; af.N = ps.N; af.dpol = w->dpol + ps.dpol_off;
-        const size_t lds = x_lds_tan_fwd(c, ps.D);
-        if (X.maxt == 768) x_launch_tan<768>(ps.D, false, grd, blkF, lds, s, ab, af);
-        else x_launch_tan<1024>(ps.D, false, grd, blkF, lds, s, ab, af);
+        fa.sy = X.sync + 2 + 2 * p + 1; fa.groups = ps.groups; fa.dpol = w->dpol + ps.dpol_off;
+        x_launch_fwd(X, ps.D, false, grd, blkF, x_lds_fwd(c, ps.D), s, fa);
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
         const int W = XG * ps.D;
         hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, W, w->dagg_pass);
@@ -738,6 +758,15 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
 static int x_status(hank_ctx *ctx) {
     XWork &X = ctx->xw;
     if (!X.ready || X.last_passes == 0) return HANK_OK;
+    int uo = 0;
+    HIPC(ctx, hipMemcpy(&uo, X.unit_overflow, sizeof(int), hipMemcpyDeviceToHost));
+    if (uo) {
+        HIPC(ctx, hipMemset(X.unit_overflow, 0, sizeof(int)));
+        ctx->primal_done = false;
+        X.rng_valid = false;
+        for (XTan &t : X.tans) t.valid = false;
+        return fail(ctx, HANK_ERR_SWEEP, "persistent forward sweep: a member's walk over its sources needs more than %d work units (a savings policy this flat is served by the per-period launches)", XUCAP);
+    }
     std::vector<XSync> h(2 * (size_t)X.last_passes);
     HIPC(ctx, hipMemcpy(h.data(), X.sync, sizeof(XSync) * h.size(), hipMemcpyDeviceToHost));
     for (size_t k = 0; k < h.size(); k++)
@@ -843,7 +872,7 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     if (se && strcmp(se, "xcd") == 0) {
         if (ctx->schedule == 0)
             return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=xcd: n_a=%d needs %d workgroups per XCD (the device has %d) and %zu bytes of LDS per workgroup (it has %zu)", c.n_a,
-                        (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG, std::max(x_lds_primal_back(c), x_lds_primal_fwd(c)), (size_t)prop.sharedMemPerBlock);
+                        (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG, std::max(x_lds_primal_back(c), x_lds_fwd(c, 1)), (size_t)prop.sharedMemPerBlock);
         ctx->schedule = 1;
         ctx->forced_xcd = true;
     }
@@ -939,7 +968,7 @@ static int run_primal(hank_ctx *ctx, double *d_agg_out) {
     ctx->ev_valid[0] = ctx->ev_valid[1] = true;
     ctx->ev_valid[4] = ctx->ev_valid[5] = false;
     ctx->primal_done = true;
-    ctx->xw.src_valid = false;
+    ctx->xw.src_valid = false; ctx->xw.rng_valid = false;
     for (TanWork &t : ctx->tws) t.valid = false;
     return HANK_OK;
 }
@@ -982,7 +1011,7 @@ static bool x_tan_fits(const hank_ctx *ctx, int N) {
     const XWork &X = ctx->xw;
     int D = 1;
     while (XG * D < N && D < X.dmax) D *= 2;
-    return std::max(x_lds_tan_back(ctx->c, D), x_lds_tan_fwd(ctx->c, D)) <= (size_t)X.lds_max;
+    return std::max(x_lds_tan_back(ctx->c, D), x_lds_fwd(ctx->c, D + 1)) <= (size_t)X.lds_max;
 }
 static bool use_x_jvp(const hank_ctx *ctx, int N) { return (ctx->schedule == 1 || (ctx->schedule == 2 && N <= ctx->xjvp_max)) && x_tan_fits(ctx, N); }
 static bool use_x_fused(const hank_ctx *ctx, int N) { return ctx->schedule == 1 && x_tan_fits(ctx, N); }      // auto: the dual-sweep launches hide the primal chain
@@ -1132,7 +1161,7 @@ static int run_fused(hank_ctx *ctx) {
     ctx->ev_valid[4] = ctx->ev_valid[5] = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
     ctx->primal_done = true;
-    ctx->xw.src_valid = false;
+    ctx->xw.src_valid = false; ctx->xw.rng_valid = false;
     for (TanWork &t : ctx->tws) t.valid = false;
     w.valid = true;
     ctx->last_tan = 0;
@@ -1267,8 +1296,8 @@ int hank_fake_news(hank_ctx *ctx, double *F_out, double *Dv_out) {
 // dev build: the stamps of the last sweeps (see hank_xsweep.h)
 int hank_debug_stamps(hank_ctx *ctx, unsigned long long *out) {
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    HIPC(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(hank::g_xstamps), sizeof(unsigned long long) * 2 * 2 * XSTAMP_NP * XSTAMP_NS));
-    HIPC(ctx, hipMemcpyFromSymbol(out + 2 * 2 * XSTAMP_NP * XSTAMP_NS, HIP_SYMBOL(hank::g_xwaves), sizeof(unsigned long long) * 2 * 2 * XSTAMP_NP * 16));
+    HIPC(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(hank::g_xstamps), sizeof(unsigned long long) * 2 * 32 * XSTAMP_NP * XSTAMP_NS));
+    HIPC(ctx, hipMemcpyFromSymbol(out + 2 * 32 * XSTAMP_NP * XSTAMP_NS, HIP_SYMBOL(hank::g_xwaves), sizeof(unsigned long long) * 2 * 32 * XSTAMP_NP * 16));
     return HANK_OK;
 }
 #endif
@@ -1468,8 +1497,7 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
         XVfiArgs va{};
         va.c = c; va.V0 = V[0]; va.r = r; va.w = w; va.tr = tr; va.tol = tol; va.max_iter = max_iter; va.sy = X.sync; va.st_s = X.st_s;
         va.err = ctx->d_err; va.Vout = V[1]; va.pol = pol; va.iters = state; va.supnorm = norm;
-        const char *swv = getenv("HANK_XSYNCWAVE");
-        const bool fits = 64 * (c.n_e + 1) <= X.maxt && !(swv && atoi(swv) == 0);
+        const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
         const dim3 xblk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e);
         const size_t lds = sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 16) + 64;
         if (X.maxt == 768) hipLaunchKernelGGL((k_xvfi<768>), dim3(X.grid), xblk, lds, s, va);
@@ -1591,8 +1619,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
         XStatArgs sa{};
         sa.c = c; sa.R = R; sa.D0 = D[0]; sa.tol = tol; sa.max_iter = max_iter; sa.check_every = check_every; sa.sy = X.sync;
         sa.st_D = X.st_D; sa.Dout = D[1]; sa.iters = state;
-        const char *swv = getenv("HANK_XSYNCWAVE");
-        const bool fits = 64 * (c.n_e + 1) <= X.maxt && !(swv && atoi(swv) == 0);
+        const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
         const dim3 xblk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e);
         const size_t lds = sizeof(double) * ((size_t)c.n_e * 64 + 16) + 64;
         if (X.maxt == 768) hipLaunchKernelGGL((k_xstat<768>), dim3(X.grid), xblk, lds, s, sa);

@@ -34,12 +34,10 @@
 // barriers, ...) is in DESIGN.md section 4.
 #pragma once
 #include "hank_kernels.h"
+#include <type_traits>
 
 namespace hank {
 
-#ifndef HANK_XFWD_NS4
-#define HANK_XFWD_NS4 3
-#endif
 constexpr int XG = 8;             // groups = XCDs
 constexpr int XRW = 63;           // wealth rows per workgroup; lane 63 of every wave is the forward sweep's virtual row
 constexpr unsigned XSPIN_LIMIT = 1u << 21;
@@ -88,6 +86,9 @@ struct XRows {
             }
         }
     }
+    __device__ __forceinline__ double load_one(size_t row, int k) const {            // slot k of a row (sc1, 8 bytes)
+        return D == 1 ? xld(base + row) : xld(base + ((size_t)(k / 2) * plane + row) * 2 + (k & 1));
+    }
     __device__ __forceinline__ void store(size_t row, const double *v) const {      // plain stores: the line stays in the XCD's L2
         if (D == 1) {
             base[row] = v[0];
@@ -128,7 +129,7 @@ struct XGroup { int x, c, S, ok; };
 // [XSTAMP_T0, XSTAMP_T0+8): where a period's time goes. Never compiled into the product library.
 #ifdef HANK_XSTAMP
 constexpr int XSTAMP_T0 = 100, XSTAMP_NP = 8, XSTAMP_NS = 12;
-__device__ unsigned long long g_xstamps[2][2][XSTAMP_NP][XSTAMP_NS];      // [sweep][member first/last][period][stamp]
+__device__ unsigned long long g_xstamps[2][32][XSTAMP_NP][XSTAMP_NS];     // [sweep][member of group 0][period][stamp]
 #define XSTAMP(sw, on, per, i)                                                                                   \
     do {                                                                                                         \
         if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && threadIdx.x == 0)                 \
@@ -141,7 +142,7 @@ __device__ unsigned long long g_xstamps[2][2][XSTAMP_NP][XSTAMP_NS];      // [sw
             g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memrealtime();                              \
     } while (0)
 // every wave's arrival at one chosen point of the period (lane 0 of each wave)
-__device__ unsigned long long g_xwaves[2][2][XSTAMP_NP][16];
+__device__ unsigned long long g_xwaves[2][32][XSTAMP_NP][16];
 #define XSTAMPV(sw, on, per)                                                                                     \
     do {                                                                                                         \
         if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (threadIdx.x & 63) == 0)          \
@@ -585,155 +586,6 @@ __global__ void __launch_bounds__(MAXT) k_xvfi(XVfiArgs A) {
     if (cW == 0 && threadIdx.x == 0) { A.iters[0] = steps; A.iters[1] = conv; *A.supnorm = gmax; }
 }
 
-struct XFwdArgs {
-    Consts c;
-    Record R;                   // pol, seg, clo, lw, ig (k_lottery ran on the policy sequence); lwg and Dseq rows 1..P are written here
-    const double *D0;           // [G] initial distribution (ForwardIteration.jl:293)
-    XSync *sy;
-    double *st_D;               // [2][XG][G + 64*n_e] state incl. the virtual rows
-    double *Dvirt;              // [P][n_e][64] the mass kept on the virtual rows, per member (added to row 0 by k_xfix_D)
-    double *aggpart;            // [P][Sact*n_e] aggregate partials
-};
-
-template <int MAXT>
-__global__ void __launch_bounds__(MAXT) k_xprimal_fwd(XFwdArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double xl[];
-    const Consts &c = A.c;
-    const Record &R = A.R;
-    const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
-    const int GV = G + 64 * ne;
-    double *tile = xl;                                  // [ne][64]
-    int *closh = reinterpret_cast<int *>(tile + (size_t)ne * 64);     // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
-    int *ctl = closh + (size_t)P * ne;
-    const XGroup g = xgroup_join(A.sy, ctl);
-    if (!g.ok) return;
-    const int x = g.x, cW = g.c;
-    if (x != 0) return;
-    const int Sact = (na + XRW - 1) / XRW;
-    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
-    if (cW >= Sact) return;
-    for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const bool syncw = wv >= ne;
-    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
-    const int e = syncw ? 0 : wv;
-    const int r0 = cW * XRW, r = r0 + lane;
-    const bool own = !syncw && lane < XRW && r < na;
-    const bool virt = !syncw && lane == 63;             // this wave's virtual row: slot cW of column e
-    const size_t pt = (size_t)e * na + (own ? r : 0);
-    const size_t slot = own ? pt : (size_t)G + (size_t)e * 64 + cW;      // where this lane's state lives (virtual lanes: the tail)
-    double pr[16];                                      // Pi[k, e] as this wave's mixing uses it
-#pragma unroll
-    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[ne * e + k] : 0.0;
-    const size_t hs = (size_t)XG * GV;                  // the other half of the ping-pong state
-    double *const sP = A.st_D;
-    // lottery geometry of this lane's row as a TARGET: sources of its first segment have bracket r-1, of its second r
-    const double a_m = c.a[own && r > 0 ? r - 1 : 0], a_0 = c.a[own ? r : 0], a_p = c.a[own && r + 1 < na ? r + 1 : na - 1];
-    const double a_top = c.a[na - 1];
-    if (own || virt) sP[slot] = own ? A.D0[pt] : 0.0;   // D_0 into state[0]
-    // this lane's own-row record of the period about to be processed, fetched between the halves of the previous barrier
-    int sg0 = 0, sg1 = 0, sg2 = 0;
-    double polr = 0.0, lwr = 0.0, igr = 0.0;
-#define XPF_PREFETCH(T)                                                                                              \
-    do {                                                                                                             \
-        const size_t pb_ = (size_t)(T) * G + (size_t)e * na;                                                         \
-        if (own) { const int4 q_ = R.seg[pb_ + r]; sg0 = q_.x; sg1 = q_.y; sg2 = q_.z; polr = R.pol[pb_ + r]; lwr = R.lw[pb_ + r]; igr = R.ig[pb_ + r]; } \
-        else if (virt) polr = R.pol[pb_];              /* a virtual row sits at the first grid point */             \
-    } while (0)
-    unsigned episode = 1;
-    xbar_arrive(!syncw);
-    XPF_PREFETCH(0);
-    xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
-    int cur = 0;
-    bool vnz = false;                                   // the virtual rows may hold mass: some column was clamped last period
-                                                        // (the exogenous transition spreads it over every column's virtual rows)
-    for (int t = 0; t < P; t++) {
-        const size_t base = (size_t)t * G + (size_t)e * na;
-        const size_t hb = (size_t)cur * hs;             // this period reads half `cur`
-        int clo = 0;
-        bool vnz_next = false;                          // some column is clamped this period (every wave reads all n_e counts)
-        for (int k = 0; k < ne; k++) vnz_next = vnz_next || closh[t * ne + k] > 0;
-        double accD = 0.0;
-        if (!syncw) {
-            clo = min(max(closh[t * ne + e], 0), na);
-            const double *Dp = sP + hb + (size_t)e * na;
-            // the mass that sits on the virtual rows of this column (needed by the targets of source 0 when row 0 is not
-            // clamped, and folded into D_{t-1}[0] there): summed by the wave, member order fixed
-            // (only a wave that owns row 0 or has a target fed by source row 0 needs it: one or two members per open column)
-            double vD = 0.0;
-            // the mass point's inputs do not depend on the gather: in flight during it
-            double cD = 0.0;
-            if (own && r < clo) cD = xld(Dp + r);
-            if (virt && clo > 0 && vnz) cD = xld(sP + hb + slot);
-            if (vnz && clo == 0 && __any(own && (r == 0 || (sg0 <= 0 && min(sg2, na) > 0)))) {
-                if (lane < Sact) vD = xld(sP + hb + (size_t)G + (size_t)e * 64 + lane);
-                vD = xwave_sum(vD);
-            }
-            if (own) {      // what the tangent sweeps read per SOURCE: {w, ig * D_{t-1}} (k_lottery's w and ig)
-                double Dfull = xld(Dp + r);
-                if (r == 0 && clo == 0) Dfull += vD;
-                R.lwg[base + r] = make_double2(lwr, igr * Dfull);
-                const int s0 = max(sg0, 0), s2 = min(sg2, na);        // (a record that is not a lottery must not turn into a long loop)
-                // sources four at a time: all their loads are in flight before the first is used
-                for (int j0 = s0; j0 < s2; j0 += 4) {
-                    double pj[4], Dj[4];
-                    bool on[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int j = j0 + u;
-                        on[u] = j < s2;
-                        pj[u] = 0.0; Dj[u] = 0.0;
-                        if (on[u]) { pj[u] = R.pol[base + j]; Dj[u] = xld(Dp + j); }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int j = j0 + u;
-                        if (!on[u]) continue;
-                        const bool first = j < sg1;                       // source's upper target is this row
-                        if (j == 0) Dj[u] += vD;     // (then clo == 0) row 0's virtual rows follow row 0's interior lottery
-                        // Young lottery of source j (ForwardIteration.jl:59-73; same expressions as k_lottery)
-                        const double al = first ? a_m : a_0, gap = first ? a_0 - a_m : a_p - a_0;
-                        double wj = (pj[u] - al) / gap;
-                        if (pj[u] > a_top) wj = 1.0;                      // all mass on the last point (:59-63)
-                        accD += (first ? wj : 1.0 - wj) * Dj[u];
-                    }
-                }
-            }
-            // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one. Each member sums
-            // ITS rows of the clamped prefix into its virtual row (never combined: everything downstream is linear); while
-            // row 0 itself is clamped the old virtual row is carried along.
-            {
-                if (clo > r0) cD = xwave_reduce63(cD);      // wave-uniform: some of this member's rows are clamped (lane 63 takes the sum)
-                if (virt) accD = cD;
-            }
-            tile[e * 64 + lane] = accD;
-        }
-        xlds_barrier();
-        vnz = vnz_next;
-        const int nxt = cur ^ 1;
-        if (!syncw) {
-            // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99)
-            double Dn;
-            xtile_mix_reg<1, 1>(tile + lane, pr, ne, &Dn);
-            if (own || virt) {
-                sP[(size_t)nxt * hs + slot] = Dn;
-                if (own) R.Dseq[(size_t)(t + 1) * G + pt] = Dn;
-                else A.Dvirt[((size_t)t * ne + e) * 64 + cW] = Dn;
-            }
-            // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307): sum(pol_t * D_t); a virtual row
-            // carries row 0's policy
-            const double pD = xwave_reduce63((own || virt) ? polr * Dn : 0.0);
-            if (lane == 63) A.aggpart[(size_t)t * Sact * ne + (size_t)cW * ne + e] = pD;
-        }
-        cur = nxt;
-        episode++;
-        xbar_arrive(!syncw);
-        if (t + 1 < P) XPF_PREFETCH(t + 1);
-        xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
-    }
-#undef XPF_PREFETCH
-}
-
 // ================================ tangent-only sweeps at a recorded primal ===================================
 // The dual sweeps above cost what the Float64 recurrence costs — and every group repeats it (bracket search, two
 // roots and four divisions per point and period: ~10x the work of one partial). At a FIXED x (the whole y-iteration,
@@ -979,7 +831,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     double cA = 0.0, cB = 0.0, cu = 0.0, cv = 0.0, ck = 0.0, cs = 0.0;
     if (own) { ck = R.kc[(size_t)(P - 1) * G + pt]; cs = R.s[(size_t)(P - 1) * G + pt]; }
     // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0); member c publishes episode i+1 when the stores of trip i have drained
-    const int son = x == 0 ? (cW == 0 ? 0 : (cW == Sact / 3 ? 1 : -1)) : -1;     // dev stamps (make stamp)
+    const int son = (x == 0 && cW < 32) ? cW : -1;     // dev stamps (make stamp)
     (void)son;
     for (int i = 0; i <= P; i++) {
         XSTAMP(0, son, i, 0);
@@ -1043,31 +895,61 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     }
 }
 
-struct XTanFwdArgs {
+// ================================ forward sweeps, source-stationary (round 4) ========================================
+// ONE kernel for the three forward recurrences (ForwardIteration.jl:297-308 and its partials):
+//   k_xfwd<0, true>  the Float64 distribution sweep: group 0 only, writes D_1..D_P, {w, ig D} and the aggregate
+//   k_xfwd<D, false> D partials per group at a recorded primal
+//   k_xfwd<D, true>  value AND D partials per group (the forward half of the Dual pass, hank_primal_jvp): every group carries
+//                    D_t itself — one more slot of the same linear step, no pow, no search — and group 0 writes the record
+// A member's period in the target-stationary form of rounds 2-3 was a gather loop per target row: 2-8 sources on one row,
+// three at a time, each trip a dependent L2 round trip, every source row fetched by both of its targets, and the workgroup
+// waited for its slowest wave. Here the SOURCES are walked: 64 source rows per instruction, each source's two lottery parts
+// added into the LDS tile of its target rows (ds_add_f64). The walk is cut into WORK UNITS in advance (k_xunits_fwd, once per
+// recorded lottery): a unit is a run of <= 64 consecutive sources of one column that feeds a run of consecutive target rows
+// of the member; a source on the seam between two units is walked by both, each adding only the part that lands in its own
+// target run — so every tile entry is written by exactly one unit, by one wave, in program order: the sum is reproducible
+// bit for bit whichever wave a unit is dealt to. Units are dealt round-robin to the member's waves, two per wave in straight-
+// line code (both in flight together; the rare member with more units loops): the wave of a column whose policy is flat — up
+// to 216 sources on 63 targets at 2000x11 — no longer holds the whole group back (stamps, DESIGN.md section 4: 3.2 us behind).
+// The mass kept on the members' virtual rows travels as extra lanes of the unit that walks source row 0 of an open column
+// (same lottery record, the members' virtual rows as state rows): no special sums. The mass point itself needs no load at
+// all: a member's clamped rows and its virtual row are its own rows of the previous period — its own registers.
+template <int NSL> struct XSlots {
+    static constexpr int SP = NSL == 1 ? 1 : ((NSL + 1) / 2) * 2;        // slots of a state row (planes of 16-byte pairs)
+    static constexpr int SL = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);      // slots of a tile entry (see XTileT)
+};
+constexpr int XUCAP = 64;       // work units per member and period (k_xunits_fwd reports an overflow; the host then uses the launches)
+struct XSweepFwdArgs {
     Consts c;
-    Record R;                   // pol, seg, clo, lwg, Dseq of the recorded primal
+    Record R;                   // pol, lo, lw, ig (k_lottery); !VAL: lwg, Dseq of the recorded primal; VAL: group 0 writes lwg, Dseq
     XSync *sy;
-    double *st_dD;              // [2][XG][G + 64*n_e][D]
-    const double *dpol;         // [P][groups][G][D]
-    int groups, N;
-    const double *Dvirt;        // [P][n_e][64] the primal's virtual mass
-    double *daggpart;           // [P][Sact*n_e][XG*D]
-    const int *src;             // [P][members] lo | hi << 8 (k_xsrc_fwd); null = all
+    double *st;                 // [2][XG][n_e*members*64][SP] the ping-pong state
+    const double *D0;           // VAL: [G] initial distribution (ForwardIteration.jl:293)
+    const double *dpol;         // D > 0: [P][groups][G][D]
+    int groups;
+    double *Dvirt;              // VAL: [P][n_e][64] the mass kept on the virtual rows (k_xfix_D)
+    double *aggpart;            // VAL: [P][members*n_e]
+    double *daggpart;           // D > 0: [P][members*n_e][XG*D]
+    const int *src;             // [P][members] lo | hi << 8 | (some column clamped) << 16 | (member 0 records row 0's full mass) << 17 | units << 18
+    const int2 *units;          // [P][members][XUCAP] {e | ja << 4 | cnt << 16, ta | tb << 8 | nv << 16}
+    int all_members;            // dev knob: every period waits for every member
 };
 
-template <int D, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
-    constexpr int SL = XTileT<D>::SL;
-    constexpr int NS = MAXT > 768 ? 2 : (D == 4 ? HANK_XFWD_NS4 : 4);      // sources per trip of the gather loop (registers)
-    constexpr bool PIREG = D < 4;                       // the mixing's coefficients in registers (D = 4 needs them for the gather)
+template <int D, bool VAL, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
+    constexpr int NSL = D + (VAL ? 1 : 0);              // live slots: the D partials, then the value
+    constexpr int SP = XSlots<NSL>::SP, SL = XSlots<NSL>::SL;
+    constexpr int IV = D;                               // the value's slot
+    constexpr int DD = D > 0 ? D : 1;
+    constexpr bool PIREG = NSL < 4;                     // the mixing's coefficients in registers
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const Record &R = A.R;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
-    double *tile = xl;
-    double *Pish = tile + (size_t)SL * ne * 64;        // [ne*ne] (read when !PIREG)
-    int *closh = reinterpret_cast<int *>(Pish + ne * ne);     // [P][ne]
-    int *srcsh = closh + (size_t)P * ne;                       // [P]: this member's source ranges
+    double *tile = xl;                                  // [ne][64][SL]
+    double *Pish = tile + (size_t)SL * ne * 64;         // [ne*ne] (read when !PIREG)
+    int *closh = reinterpret_cast<int *>(Pish + ne * ne);       // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
+    int *srcsh = closh + (size_t)P * ne;                // [P]
     int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
@@ -1076,181 +958,345 @@ __global__ void __launch_bounds__(MAXT) k_xtan_fwd(XTanFwdArgs A) {
     const int Sact = (na + XRW - 1) / XRW;
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
+    const bool rec = VAL && x == 0;                     // this group writes the record
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
-    for (int k = threadIdx.x; k < P; k += blockDim.x) srcsh[k] = A.src ? A.src[(size_t)k * Sact + cW] : ((Sact - 1) << 8);
+    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+        int w = A.src[(size_t)k * Sact + cW];
+        if (A.all_members || (rec && ((w >> 17) & 1))) w = (w & ~0xffff) | ((Sact - 1) << 8);
+        srcsh[k] = w;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool syncw = wv >= ne;                        // see k_xtan_back
     const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
     const int e = syncw ? 0 : wv;
     const int r0 = cW * XRW, r = r0 + lane;
     const bool own = !syncw && lane < XRW && r < na;
-    const bool virt = !syncw && lane == 63;
-    // state layout [e][member][64][D]: a member's 63 rows and its virtual row (slot 63) are ONE line-aligned block of its
-    // column, written by one store instruction of one wave — no line is shared between two workgroups' partial writes
-    // (the reads of such lines took an HBM round trip: 1.8 us for the virtual rows of a column)
-    const size_t GV = (size_t)ne * Sact * 64;
-    const size_t gx = (size_t)x * GV;                   // this group's rows within a half of the ping-pong buffer
+    const bool virt = !syncw && lane == 63;             // this wave's virtual row: part of the mass point (row 0) kept by this member
+    const bool live = own || virt;
+    const size_t pt = (size_t)e * na + (own ? r : 0);
+    // state layout [e][member][64][SP]: a member's 63 rows and its virtual row (slot 63) are ONE line-aligned block
+    const size_t GM = (size_t)ne * Sact * 64;
+    const size_t gx = (size_t)x * GM;
     const size_t slot = gx + ((size_t)e * Sact + cW) * 64 + lane;
+    const size_t hs = (size_t)XG * GM;
     double pr[16];                                      // Pi[k, e] as this wave's mixing uses it
 #pragma unroll
     for (int k = 0; k < 16; k++) pr[k] = (PIREG && k < ne) ? c.Pi[ne * e + k] : 0.0;
-    const size_t hs = (size_t)XG * GV;
-    XRows<D> rows;
-    rows.init(A.st_dD, 2 * hs);
+    XRows<SP> rows;
+    rows.init(A.st, 2 * hs);
     double *const myt = tile + ((size_t)e * 64 + lane) * SL;
+    double mxp[NSL];                                    // this lane's row of the previous period (the state it stored)
+#pragma unroll
+    for (int k = 0; k < NSL; k++) mxp[k] = 0.0;
+    if constexpr (VAL) { if (own) mxp[IV] = A.D0[pt]; }
     {
-        double z[D];
+        double sv[SP];
 #pragma unroll
-        for (int k = 0; k < D; k++) z[k] = 0.0;
-        if (own || virt) rows.store(slot, z);           // the initial distribution carries no partials
+        for (int k = 0; k < SP; k++) sv[k] = k < NSL ? mxp[k] : 0.0;
+        if (live) rows.store(slot, sv);                 // D_0; it carries no partials
     }
-    // this lane's own-row record of the period about to be processed (segments, policy, D_t, policy partials): fetched
-    // between the two halves of the previous group barrier
-    int4 sg = make_int4(0, 0, 0, 0);
-    double polr = 0.0, Dr = 0.0, dpr[D];
+    // this lane's own-row record of the period about to be processed (what the aggregate and the record need). At a recorded
+    // primal the term dpol_t D_t of the aggregate is taken where the policy partials are loaded anyway — at the SOURCE rows —
+    // and a row's own partials only count where the row is clamped (not walked as a source: its partial is zero except on a
+    // knot tie). Branch-free on purpose: these loads are part of the counted batch behind the period's stores (see XFWD_NLD).
+    double polr = 0.0, Dr = 0.0, lwr = 0.0, igr = 0.0, dpr[DD];
 #pragma unroll
-    for (int k = 0; k < D; k++) dpr[k] = 0.0;
+    for (int k = 0; k < DD; k++) dpr[k] = 0.0;
     auto prefetch = [&](int t) {
-        if (own) {
-            const size_t base = (size_t)t * G + (size_t)e * na;
-            sg = R.seg[base + r];
-            polr = R.pol[base + r];
-            Dr = R.Dseq[base + G + r];                         // D_t[r] (row 0 includes what the primal kept on its virtual rows)
-            xload_row_plain<D>(A.dpol + (((size_t)t * A.groups + x) * G + (size_t)e * na + r) * D, dpr);
-            // this row is somebody's SOURCE next period: its lottery record is only ever read as a source (cold from HBM
-            // inside the source loop otherwise) — touching it here puts the line into the XCD's L2 for whoever needs it
-            const double2 wtouch = R.lwg[base + r];
-            asm volatile("" ::"v"(wtouch.x), "v"(wtouch.y));
-        } else if (virt) {                                      // a virtual row carries row 0's policy
-            polr = R.pol[(size_t)t * G + (size_t)e * na];
-        }
+        const size_t ro = (size_t)t * G + (size_t)e * na + (own ? r : 0);       // (a virtual row carries row 0's policy and partials)
+        polr = R.pol[ro];
+        if constexpr (D > 0) xload_row_plain<DD>(A.dpol + ((size_t)t * A.groups + x) * (size_t)G * D + ((size_t)e * na + (own ? r : 0)) * D, dpr);
+        if constexpr (VAL) { lwr = R.lw[ro]; igr = R.ig[ro]; }
+        else { if constexpr (D > 0) Dr = R.Dseq[ro + G]; }      // D_t[r] (row 0 includes what the primal kept on its virtual rows)
     };
-    xbar_arrive(!syncw);                                // the zeroed state has reached L2: episode 1
+    // ---- the two work units of this wave, register sets 0 and 1: per lane a source's lottery record {lo, w, ig D_{t-1} | ig},
+    // its policy partials and (at a recorded primal) D_t of its row; then its state row
+    int2 ud[2];                                         // the units' descriptors (wave-uniform)
+    int qlo[2];
+    double qw[2], qg[2], qdn[2], qdp[2][DD], dd[2][SP];
+    bool qon[2], qvl[2];
+    const int2 *const ubase = A.units + (size_t)cW * XUCAP;
+    auto unit_desc = [&](int t, int u) -> int2 {        // unit u of this member in period t (u wave-uniform): broadcast load -> scalar registers
+        const int2 q = ubase[(size_t)t * Sact * XUCAP + u];
+        return make_int2(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y));
+    };
+    // (branch-free: every lane loads — a lane beyond the unit's sources the unit's last row, an empty unit row 0 of column 0 — and
+    // qon / qvl say what counts)
+    auto load_rec = [&](auto U, int t, int2 d, int i0) {
+        constexpr int u = decltype(U)::value;
+        const int ue = d.x & 15, ja = (d.x >> 4) & 0xfff, cnt = (d.x >> 16) & 0xfff, nv = (d.y >> 16) & 0xff;
+        const int i = i0 + lane;
+        const bool real = i < cnt;
+        qvl[u] = !real && i < cnt + nv;                 // a member's virtual row riding on source row 0's record
+        qon[u] = real || qvl[u];
+        const size_t cb = (size_t)t * G + (size_t)ue * na;
+        const int j = real ? ja + i : (qvl[u] ? 0 : min(ja + max(cnt - 1, 0), na - 1));
+        qlo[u] = R.lo[cb + j];
+        if constexpr (VAL) { qw[u] = R.lw[cb + j]; if constexpr (D > 0) qg[u] = R.ig[cb + j]; }       // (ig only weights the policy partials)
+        else { const double2 wg = R.lwg[cb + j]; qw[u] = wg.x; qg[u] = wg.y; if constexpr (D > 0) qdn[u] = R.Dseq[cb + G + j]; }
+        if constexpr (D > 0) xload_row_plain<DD>(A.dpol + (((size_t)t * A.groups + x) * G + (size_t)ue * na + j) * D, qdp[u]);
+    };
+    auto load_state = [&](auto U, size_t hb, int2 d, int i0) {
+        constexpr int u = decltype(U)::value;
+        const int ue = d.x & 15, ja = (d.x >> 4) & 0xfff, cnt = (d.x >> 16) & 0xfff;
+#pragma unroll
+        for (int k = 0; k < SP; k++) dd[u][k] = 0.0;
+        const int i = i0 + lane, j = ja + i;
+        const size_t row = qvl[u] ? ((size_t)ue * Sact + (i - cnt)) * 64 + 63 : ((size_t)ue * Sact + j / XRW) * 64 + j % XRW;
+        if (qon[u]) rows.load(hb + gx + row, dd[u]);
+    };
+    const std::integral_constant<int, 0> I0;
+    const std::integral_constant<int, 1> I1;
+    int2 udn[2];                                        // the descriptors of the period after next, on their way (loaded a period ahead: cold lines)
+    bool udv[2] = {false, false};                       // ... and whether this wave has such a unit at all
+    udn[0] = udn[1] = make_int2(0, 0);
+    auto request_units = [&](int t) {                   // this wave's two units of period t (branch-free: an index that exists is loaded anyway)
+        const int tc = min(t, P - 1);
+        int nu = (srcsh[tc] >> 18) & 0xff;
+        nu = t < P ? nu : 0;
+        udv[0] = wv < nu; udv[1] = wv + ne < nu;
+        udn[0] = ubase[(size_t)tc * Sact * XUCAP + (udv[0] ? wv : 0)];
+        udn[1] = ubase[(size_t)tc * Sact * XUCAP + (udv[1] ? wv + ne : 0)];
+    };
+    auto take_units = [&]() {
+        ud[0] = udv[0] ? make_int2(__builtin_amdgcn_readfirstlane(udn[0].x), __builtin_amdgcn_readfirstlane(udn[0].y)) : make_int2(0, 0);
+        ud[1] = udv[1] ? make_int2(__builtin_amdgcn_readfirstlane(udn[1].x), __builtin_amdgcn_readfirstlane(udn[1].y)) : make_int2(0, 0);
+    };
+    // The loads of the NEXT period — its two units' records, the own-row record, the descriptors of the period after — are cold
+    // lines of the record (2.4 us from HBM under this load) and vector-memory waits are in order: behind an ordinary drain
+    // (vmcnt(0) before the group barrier) they cost their whole latency every period. They are therefore issued AFTER the
+    // period's last store, as a batch of exactly XFWD_NLD instructions, every one of them unconditional, and the drain waits
+    // with vmcnt(XFWD_NLD): everything older than the batch — the stores — has completed, the batch itself stays in flight
+    // through the publish, the next poll and the next state loads (tests/test_isa_hazards.py counts the instructions between
+    // the two markers in the ISA against the immediate).
+    constexpr int DPI = D == 0 ? 0 : (D <= 2 ? 1 : D / 2);                 // load instructions per row of policy partials
+    constexpr int XFWD_NLD = 2 * (1 + (VAL ? (D > 0 ? 2 : 1) : 1 + (D > 0 ? 1 : 0)) + DPI) + (1 + DPI + (VAL ? 2 : (D > 0 ? 1 : 0))) + 2;
+    auto next_period_loads = [&](int t) {               // t: the period that has just been stored (ud holds the NEXT period's units by now)
+        const int t1 = min(t + 1, P - 1);
+        load_rec(I0, t1, ud[0], 0);
+        load_rec(I1, t1, ud[1], 0);
+        prefetch(t1);
+        request_units(t + 2);
+    };
+    xbar_arrive(!syncw);                                // the initial state has reached L2: episode 1
     if (sync_duty) xpublish(A.sy, x, cW, 1u);
-    prefetch(0);
+    ud[0] = ud[1] = make_int2(0, 0);
+    if (!syncw) { request_units(0); take_units(); load_rec(I0, 0, ud[0], 0); load_rec(I1, 0, ud[1], 0); prefetch(0); request_units(1); }
     int cur = 0;
-    bool vnz = false;
-    const int son = x == 0 ? (cW == 0 ? 0 : (cW == Sact / 3 ? 1 : -1)) : -1;     // dev stamps (make stamp)
+    bool vnz = false;                                   // the virtual rows may hold mass: some column was clamped last period
+    const int son = (x == 0 && cW < 32) ? cW : -1;     // dev stamps (make stamp)
     (void)son;
     for (int t = 0; t < P; t++) {
         XSTAMP(1, son, t, 0);
-        XSTAMPW(1, son, t, 9, ne / 2);
-        XSTAMPW(1, son, t, 10, ne - 1);
         const size_t base = (size_t)t * G + (size_t)e * na;
         const size_t hb = (size_t)cur * hs;
-        const size_t dbase = ((size_t)t * A.groups + x) * G + (size_t)e * na;
+        const int sw = srcsh[t];
         int clo = 0;
-        bool vnz_next = false;
-        for (int k = 0; k < ne; k++) vnz_next = vnz_next || closh[t * ne + k] > 0;
-        double acc[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) acc[k] = 0.0;
-        if (sync_duty) xpoll(A.sy, x, srcsh[t] & 255, srcsh[t] >> 8, (unsigned)(t + 1));   // this period's source members have published period t-1
-        XSTAMPW(1, son, t, 7, ne);
-        xlds_barrier();
-        XSTAMP(1, son, t, 1);
         if (!syncw) {
             clo = min(max(closh[t * ne + e], 0), na);
-            // the partials sitting on this column's virtual rows follow source row 0's lottery: only a wave with a target fed
-            // by row 0 needs their sum (one or two members per open column). Its loads fly during the gather, the sum (DPP,
-            // fixed order) enters with row 0's weight after it.
-            const bool need_vT = vnz && clo == 0 && __any(own && sg.x <= 0 && min(sg.z, na) > 0);
-            double vT[D], w0 = 0.0;
+            double z[SL];
 #pragma unroll
-            for (int k = 0; k < D; k++) vT[k] = 0.0;
-            if (need_vT && lane < Sact) rows.load(hb + gx + ((size_t)e * Sact + lane) * 64 + 63, vT);
-            // the mass point's inputs (this member's clamped rows, its own virtual row): in flight during the gather as well
-            double cT[D];
+            for (int k = 0; k < SL; k++) z[k] = 0.0;
+            xtile_store<SL>(myt, z);                    // (every wave is past the previous period's mixing: xbar_arrive)
+        }
+        if (sync_duty) xpoll(A.sy, x, sw & 255, (sw >> 8) & 255, (unsigned)(t + 1));   // this period's source members have published period t-1
+        xlds_barrier();
+        XSTAMP(1, son, t, 1);
+        double pagg[DD];
 #pragma unroll
-            for (int k = 0; k < D; k++) cT[k] = 0.0;
-            if (own && r < clo) rows.load(hb + slot, cT);
-            if (virt && clo > 0 && vnz) rows.load(hb + slot, cT);
-            if (own) {
-                const int s0 = max(sg.x, 0), s2 = min(sg.z, na);   // (a record that is not a lottery must not turn into a long loop)
-                // sources NS at a time: all their loads are in flight before the first is used (a wave's gather costs one
-                // L2 round trip per trip of this loop, and the workgroup waits for its slowest wave: 3 sources on some row of
-                // most columns, up to 8 where high-income households leave the bottom of the grid)
-                for (int j0 = s0; j0 < s2; j0 += NS) {
-                    double2 wg[NS];
-                    double dDj[NS][D], dpj[NS][D];
-                    bool on[NS];
+        for (int k = 0; k < DD; k++) pagg[k] = 0.0;
+        double v0 = 0.0;                                // the record's row 0: the mass on every member's virtual row of this column
+        if (!syncw) {
+            const bool need0 = rec && r0 == 0 && vnz && clo == 0;      // (wave-uniform)
+            if constexpr (VAL) {
+                if (need0 && lane < Sact) v0 = rows.load_one(hb + gx + ((size_t)e * Sact + lane) * 64 + 63, IV);
+            }
+            load_state(I0, hb, ud[0], 0);
+            load_state(I1, hb, ud[1], 0);
+            // Young lottery of a source (ForwardIteration.jl:59-73): (1-w) to row lo, w to row lo+1; the weight's partial is
+            // dpol / gap (zero where clamped), times D_{t-1} of the row. Only the parts that land in the unit's own target run
+            // [ta, tb) are added (the other part of a seam source belongs to the neighbouring unit).
+            auto process = [&](auto U, int2 d) {
+                constexpr int u = decltype(U)::value;
+                if (!qon[u]) return;
+                const int ta = d.y & 0xff, tb = (d.y >> 8) & 0xff;
+                double *const colt = tile + (size_t)(d.x & 15) * 64 * SL;
+                const double w = qw[u], w1 = 1.0 - w;
+                double gD = qg[u], Dv = 0.0;
+                if constexpr (VAL) { Dv = dd[u][IV]; gD = qg[u] * Dv; }
+                else { if (qvl[u]) gD = 0.0; }          // (a virtual row's mass is part of the recorded ig * D of row 0)
+                const int tl = qlo[u] - r0, th = tl + 1;
+                if (tl >= ta && tl < tb) {              // (every unclamped source has exactly one lower target: its aggregate term is taken here, once)
+                    double *tp = colt + (size_t)tl * SL;
 #pragma unroll
-                    for (int u = 0; u < NS; u++) {
-                        const int j = j0 + u;
-                        on[u] = j < s2;
-                        wg[u] = make_double2(0.0, 0.0);
+                    for (int k = 0; k < D; k++) lds_add(tp + k, w1 * dd[u][k] - gD * qdp[u][k]);
+                    if constexpr (VAL) lds_add(tp + IV, w1 * Dv);
+                    if constexpr (!VAL) {
+                        if (!qvl[u]) {
 #pragma unroll
-                        for (int k = 0; k < D; k++) dDj[u][k] = dpj[u][k] = 0.0;
-                        if (on[u]) {
-                            wg[u] = R.lwg[base + j];
-                            rows.load(hb + gx + ((size_t)e * Sact + j / XRW) * 64 + j % XRW, dDj[u]);
-                            xload_row_plain<D>(A.dpol + (dbase + j) * D, dpj[u]);
+                            for (int k = 0; k < D; k++) pagg[k] += qdp[u][k] * qdn[u];
                         }
                     }
+                }
+                if (th >= ta && th < tb) {
+                    double *tp = colt + (size_t)th * SL;
 #pragma unroll
-                    for (int u = 0; u < NS; u++) {
-                        const int j = j0 + u;
-                        if (!on[u]) continue;
-                        const bool first = j < sg.y;
-                        const double wt = first ? wg[u].x : 1.0 - wg[u].x;
-                        if (j == 0) w0 = wt;
-#pragma unroll
-                        for (int k = 0; k < D; k++) acc[k] += first ? (wt * dDj[u][k] + wg[u].y * dpj[u][k]) : (wt * dDj[u][k] - wg[u].y * dpj[u][k]);
-                    }
+                    for (int k = 0; k < D; k++) lds_add(tp + k, w * dd[u][k] + gD * qdp[u][k]);
+                    if constexpr (VAL) lds_add(tp + IV, w * Dv);
+                }
+            };
+            process(I0, ud[0]);
+            process(I1, ud[1]);
+            // (rare) a unit wider than a wave — more than 64 sources on ONE target row — and units beyond the member's 2 n_e slots
+            const int nu = (sw >> 18) & 0xff;
+            for (int u2 = wv; u2 < nu; u2 += ne) {
+                const int2 d = u2 < 2 * ne ? ud[u2 >= ne ? 1 : 0] : unit_desc(t, u2);
+                const int tot = ((d.x >> 16) & 0xfff) + ((d.y >> 16) & 0xff);
+                for (int i0 = u2 < 2 * ne ? 64 : 0; i0 < tot; i0 += 64) {
+                    load_rec(I0, t, d, i0);
+                    load_state(I0, hb, d, i0);
+                    process(I0, d);
                 }
             }
-            if (need_vT) {
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    const double sv = xwave_reduce63(vT[k]);        // valid in lane 63
-                    const double sb = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sv), 63), __builtin_amdgcn_readlane(__double2loint(sv), 63));
-                    acc[k] += w0 * sb;
-                }
-            }
+            if constexpr (VAL) { if (need0) v0 = xwave_sum(v0); }
+            take_units();                               // the next period's descriptors (requested a period ago; this wave's loads have all landed here)
             XSTAMP(1, son, t, 2);
-            {   // the mass point (see k_xprimal_fwd)
-                if (clo > r0) {
+            // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one and no weight
+            // partial. Each member sums ITS clamped rows into its virtual row (never combined: everything downstream is
+            // linear); while row 0 itself is clamped the old virtual row is carried along.
+            double cT[NSL];
 #pragma unroll
-                    for (int k = 0; k < D; k++) cT[k] = xwave_reduce63(cT[k]);
-                }
-                if (virt) {
+            for (int k = 0; k < NSL; k++) cT[k] = ((own && r < clo) || (virt && clo > 0 && vnz)) ? mxp[k] : 0.0;
+            if (clo > r0) {
 #pragma unroll
-                    for (int k = 0; k < D; k++) acc[k] = cT[k];
-                }
+                for (int k = 0; k < NSL; k++) cT[k] = xwave_reduce63(cT[k]);
             }
-            xtile_store_n<SL, D>(myt, acc);
+            if (virt) xtile_store_n<SL, NSL>(myt, cT);
         }
         XSTAMP(1, son, t, 3);
         XSTAMPV(1, son, t);
         if (sync_duty) xpoll(A.sy, x, 0, Sact - 1, (unsigned)(t + 1));      // EVERY member is done reading the half about to be overwritten
-        XSTAMPW(1, son, t, 8, ne);
         xlds_barrier();
         XSTAMP(1, son, t, 4);
-        vnz = vnz_next;
+        vnz = ((sw >> 16) & 1) != 0;
         const int nxt = cur ^ 1;
         if (!syncw) {
-            double mx[D];
-            if (PIREG) xtile_mix_reg<SL, D>(tile + (size_t)lane * SL, pr, ne, mx);
-            else xtile_mix<SL, D>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
-            if (own || virt) rows.store((size_t)nxt * hs + slot, mx);
-            // aggregate partials: pol_t dD_t + dpol_t D_t on real rows; a virtual row carries row 0's policy, its share of
-            // D_t[0] is already in the recorded D_t[0]
-            const bool live = own || virt;
+            // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99), value and partials in one pass
+            double mx[NSL];
+            if (PIREG) xtile_mix_reg<SL, NSL>(tile + (size_t)lane * SL, pr, ne, mx);
+            else xtile_mix<SL, NSL>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
+            if (live) {
+                double sv[SP];
+#pragma unroll
+                for (int k = 0; k < SP; k++) sv[k] = k < NSL ? mx[k] : 0.0;
+                rows.store((size_t)nxt * hs + slot, sv);
+            }
             const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
+            if constexpr (VAL) {
+                if (rec) {
+                    if (own) {
+                        R.Dseq[(size_t)(t + 1) * G + pt] = mx[IV];
+                        // what the tangent sweeps read per SOURCE: {w, ig * D_{t-1}} (k_lottery's w and ig)
+                        double Dfull = mxp[IV];
+                        if (r == 0 && clo == 0) Dfull += v0;
+                        R.lwg[base + r] = make_double2(lwr, igr * Dfull);
+                    } else if (virt) {
+                        A.Dvirt[((size_t)t * ne + e) * 64 + cW] = mx[IV];
+                    }
+                    // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307); a virtual row carries row 0's policy
+                    const double pD = xwave_reduce63(live ? polr * mx[IV] : 0.0);
+                    if (lane == 63) A.aggpart[pb] = pD;
+                }
+            }
+            // aggregate partials: pol_t dD_t + dpol_t D_t. Value carried: a row's own policy partials meet its new D_t here (a
+            // virtual row carries row 0's policy and row 0's partials). At a recorded primal: the second term was taken at the
+            // source rows (pagg), clamped rows add theirs here, and a virtual row's share of D_t[0] is in the recorded D_t[0].
 #pragma unroll
             for (int k = 0; k < D; k++) {
-                const double pd = xwave_reduce63(live ? (polr * mx[k] + (own ? dpr[k] * Dr : 0.0)) : 0.0);
+                double term = live ? polr * mx[k] : 0.0;
+                if constexpr (VAL) term = live ? (polr * mx[k] + dpr[k] * mx[IV]) : 0.0;
+                else term = (term + pagg[k]) + ((own && r < clo) ? dpr[k] * Dr : 0.0);
+                const double pd = xwave_reduce63(term);
                 if (lane == 63) A.daggpart[pb * (size_t)(XG * D) + x * D + k] = pd;
             }
+#pragma unroll
+            for (int k = 0; k < NSL; k++) mxp[k] = mx[k];
         }
         cur = nxt;
         XSTAMP(1, son, t, 5);
-        xbar_arrive(!syncw);                            // this member's stores have reached L2: episode t+2
-        if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(t + 2));
-        XSTAMPW(1, son, t, 11, ne);
+        if (!syncw) {
+            asm volatile("; XFWD_BATCH_BEGIN" ::: "memory");
+            next_period_loads(t);
+            asm volatile("; XFWD_BATCH_END\n\ts_waitcnt vmcnt(%0)" ::"n"(XFWD_NLD) : "memory");       // this member's stores have reached L2 ...
+        }
+        xlds_barrier();
+        if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(t + 2));                                       // ... episode t+2
         XSTAMP(1, son, t, 6);
-        if (t + 1 < P) prefetch(t + 1);
+    }
+}
+
+// the forward sweeps' work units from the lottery record (see k_xfwd), one block per (period, member): thread e cuts column
+// e's walk over the sources of the member's target rows into units — a run [ta, tb) of target rows (relative to the member's
+// first row) and the <= 64 consecutive sources [ja, ja + cnt) whose brackets touch it; the unit that walks source row 0 of an
+// open column while the virtual rows hold mass gets `nv` = members extra lanes (see k_xfwd). Units are numbered column by
+// column; unit u goes to wave u mod n_e. Per (period, member) also: the members its sources belong to (lo | hi << 8), whether
+// some column is clamped in the period (<< 16: the virtual rows hold mass in the next one), whether member 0 needs every
+// member's virtual row for the record of row 0 (<< 17), and the unit count (<< 18).
+__global__ void k_xunits_fwd(Consts c, Record R, int Sact, int *src, int2 *units, int *overflow) {
+    __shared__ int2 su[16][XUCAP];
+    __shared__ int scnt[16], slo, shi, sany0;
+    const int t = blockIdx.x, m = blockIdx.y, ne = c.n_e, na = c.n_a;
+    const int r0 = m * XRW, nrows = min(XRW, na - r0);
+    if (threadIdx.x == 0) { slo = m; shi = m; sany0 = 0; }
+    __syncthreads();
+    bool vnz = false;
+    if (t > 0)
+        for (int e = 0; e < ne; e++) vnz = vnz || R.clo[(size_t)(t - 1) * ne + e] > 0;
+    if ((int)threadIdx.x < ne) {
+        const int e = threadIdx.x;
+        const int *st = R.start + ((size_t)t * ne + e) * (na + 1);
+        const int clo = R.clo[(size_t)t * ne + e];
+        auto S = [&](int rr) { return min(max(st[min(max(rr, 0), na)], 0), na); };     // (a record that is not a lottery must not turn into a long walk or an out-of-range row)
+        int n = 0, ta = 0;
+        while (ta < nrows && n < XUCAP) {
+            const int ja = S(r0 + ta - 1 < 0 ? 0 : r0 + ta - 1);
+            const bool has0 = ja == 0 && clo <= 0 && vnz;        // (then source row 0 is the unit's first lane, if it has any)
+            int tb = ta + 1;
+            int cnt = max(S(r0 + tb) - ja, 0);
+            const int nv0 = (has0 && cnt > 0) ? Sact : 0;
+            while (tb < nrows) {
+                const int c2 = max(S(r0 + tb + 1) - ja, 0);
+                if (c2 + ((has0 && c2 > 0) ? Sact : 0) > 64) break;
+                tb++; cnt = c2;
+            }
+            const int nv = (has0 && cnt > 0) ? Sact : 0;
+            (void)nv0;
+            if (cnt > 0) {
+                su[e][n++] = make_int2(e | (ja << 4) | (cnt << 16), ta | (tb << 8) | (nv << 16));
+                atomicMin(&slo, ja / XRW); atomicMax(&shi, (ja + cnt - 1) / XRW);
+                if (nv) sany0 = 1;
+            }
+            ta = tb;
+        }
+        if (ta < nrows) atomicExch(overflow, 1);
+        scnt[e] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0, anyclo = 0, anyopen = 0;
+        for (int e = 0; e < ne; e++) {
+            for (int k = 0; k < scnt[e]; k++) {
+                if (tot < XUCAP) units[((size_t)t * Sact + m) * XUCAP + tot] = su[e][k];
+                tot++;
+            }
+            if (R.clo[(size_t)t * ne + e] > 0) anyclo = 1; else anyopen = 1;
+        }
+        if (tot > XUCAP) { atomicExch(overflow, 1); tot = XUCAP; }
+        int ml = min(slo, m), mh = max(shi, m);
+        if (sany0) { ml = 0; mh = Sact - 1; }           // the units with virtual lanes read every member's virtual row
+        const int allv = (m == 0 && vnz && anyopen) ? 1 : 0;
+        src[(size_t)t * Sact + m] = ml | (mh << 8) | (anyclo << 16) | (allv << 17) | (tot << 18);
     }
 }
 
@@ -1274,38 +1320,6 @@ __global__ void k_xsrc_back(Consts c, Record R, int Sact, int *src) {
         src[(size_t)t * Sact + m] = ml | (mh << 8);
     }
 }
-// the same for the forward sweep: the lottery segments of the member's target rows; when the virtual rows move through
-// source 0's lottery (some column was clamped last period, a column is not clamped now) their targets read EVERY member's slot
-__global__ void k_xsrc_fwd(Consts c, Record R, int Sact, int *src) {
-    __shared__ int smin[256], smax[256], any0;
-    const int t = blockIdx.x, m = blockIdx.y;
-    const int r0 = m * XRW, rows = min(XRW, c.n_a - r0);
-    int lo = 1 << 30, hi = -1, fed0 = 0;
-    if (threadIdx.x == 0) any0 = 0;
-    __syncthreads();
-    for (int k = threadIdx.x; k < rows * c.n_e; k += blockDim.x) {
-        const int e = k / rows, r = r0 + (k - e * rows);
-        const int4 sg = R.seg[(size_t)t * c.G + (size_t)e * c.n_a + r];
-        const int s0 = max(sg.x, 0), s2 = min(sg.z, c.n_a);
-        if (s2 > s0) { lo = min(lo, s0); hi = max(hi, s2 - 1); }
-        // a target fed by source row 0 of an open column also takes what sits on EVERY member's virtual rows of that column
-        if (s2 > s0 && s0 == 0 && R.clo[(size_t)t * c.n_e + e] <= 0) fed0 = 1;
-    }
-    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
-    if (fed0) atomicOr(&any0, 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < (int)blockDim.x; k++) { lo = min(lo, smin[k]); hi = max(hi, smax[k]); }
-        int ml = m, mh = m;
-        if (hi >= 0) { ml = min(m, lo / XRW); mh = max(m, hi / XRW); }
-        bool vnz = false;
-        for (int e = 0; e < c.n_e; e++)
-            if (t > 0 && R.clo[(size_t)(t - 1) * c.n_e + e] > 0) vnz = true;
-        if (vnz && any0) { ml = 0; mh = Sact - 1; }
-        src[(size_t)t * Sact + m] = ml | (mh << 8);
-    }
-}
-
 // rho_t = 1/(1+r_t) for every period (the X half's discounting; same expression as egm_X)
 __global__ void k_xrho(const double *xhh, int n_hh, int P, double *rho) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
