@@ -464,24 +464,17 @@ static size_t x_lds_tan_back(const Consts &c, int D) {
     const int SLt = D == 4 ? 6 : D;      // XTileT<D>::SL
     return sizeof(double) * ((size_t)SLt * c.n_e * 64 + c.P + 1 + 3 * (size_t)c.P * D) + sizeof(int) * (size_t)c.P + 64;
 }
-// k_xfwd<D, VAL>: tile (D partials + the value), Pi, the dealt units of two periods, the LDS staging of 2 n_e units' source
-// records (XStage<D, VAL>), and the clamped prefixes / source members of every period
-static size_t x_stage_size(int D, bool val) {
-    return 256 + (val ? 512 : 1024) + (D > 0 ? 512 : 0) + (D == 0 ? 0 : (D == 1 ? 512 : (size_t)512 * D));
-}
-static size_t x_lds_fwd(const Consts &c, int D, bool val) {
-    const int NSL = D + (val ? 1 : 0);
+// k_xfwd with NSL live slots (the D partials + the value): tile, Pi, {source range, clamped prefix} and source members of every period
+static size_t x_lds_fwd(const Consts &c, int NSL) {
     const int SLt = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);      // XSlots<NSL>::SL
-    const size_t n2 = (size_t)c.n_e * c.n_e;
-    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + n2 + (n2 & 1)) + 512 + 2 * (size_t)c.n_e * x_stage_size(D, val) +
-           sizeof(int) * ((size_t)c.P * c.n_e + c.P) + 128;
+    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * ((size_t)c.P * c.n_e + c.P) + 64;
 }
 // the grid fits the XCD-local schedule: a 63-row slab per CU of an XCD, and the Float64 sweeps' LDS (which holds the
 // per-period inputs of the WHOLE horizon) fits a workgroup
 static bool x_supported(const hank_ctx *ctx, int cus, size_t lds_max) {
     const Consts &c = ctx->c;
     const int Sact = (c.n_a + XRW - 1) / XRW;
-    return cus >= XG && Sact <= cus / XG && c.n_e <= 14 && std::max(x_lds_primal_back(c), x_lds_fwd(c, 0, true)) <= lds_max;
+    return cus >= XG && Sact <= cus / XG && c.n_e <= 16 && std::max(x_lds_primal_back(c), x_lds_fwd(c, 1)) <= lds_max;
 }
 
 static void x_free_tan(XTan &w) {
@@ -602,24 +595,19 @@ static void x_launch_tan_back(int D, dim3 grd, dim3 blk, size_t lds, hipStream_t
     else if (D == 4) { if constexpr (MAXT == 768) hipLaunchKernelGGL((k_xtan_back<4, MAXT>), grd, blk, lds, s, ab); }
 }
 
-// k_xfwd<D, VAL>: D = 0 (the Float64 sweep alone, VAL), 1, 2, 4. One variant (<= 128 registers): n_e column waves, the polling
-// wave and up to four loader waves make a block of up to 1024 threads
-static void x_launch_fwd(const XWork &X, int D, bool val, dim3 grd, int n_e, size_t lds, hipStream_t s, const XSweepFwdArgs &a) {
-    const int NL = std::min(4, 15 - n_e);
-    const dim3 blk(64 * (n_e + 1 + NL));
-    // (more than 64 KB of dynamic LDS needs the opt-in, once per kernel)
-#define XF(DV, VV)                                                                                                        \
-    do {                                                                                                                  \
-        static bool optin = false;                                                                                        \
-        if (!optin) { (void)hipFuncSetAttribute((const void *)(k_xfwd<DV, VV, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); optin = true; } \
-        hipLaunchKernelGGL((k_xfwd<DV, VV, 1024>), grd, blk, lds, s, a);                                                   \
-    } while (0)
+// k_xfwd<D, VAL>: D = 0 (the Float64 sweep alone, VAL), 1, 2, 4
+template <int MAXT>
+static void x_launch_fwd(int D, bool val, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XSweepFwdArgs &a) {
+#define XF(DV, VV) hipLaunchKernelGGL((k_xfwd<DV, VV, MAXT>), grd, blk, lds, s, a)
     if (D == 0) XF(0, true);
     else if (D == 1) { if (val) XF(1, true); else XF(1, false); }
     else if (D == 2) { if (val) XF(2, true); else XF(2, false); }
-    else if (D == 4) { if (val) XF(4, true); else XF(4, false); }
+    else if (D == 4) { if constexpr (MAXT == 768) { if (val) XF(4, true); else XF(4, false); } }
 #undef XF
-    (void)X;
+}
+static void x_launch_fwd(const XWork &X, int D, bool val, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XSweepFwdArgs &a) {
+    if (X.maxt == 768) x_launch_fwd<768>(D, val, grd, blk, lds, s, a);
+    else x_launch_fwd<1024>(D, val, grd, blk, lds, s, a);
 }
 // the forward sweeps' geometry at the recorded lottery (once per primal)
 static void x_ensure_rng(hank_ctx *ctx) {
@@ -664,7 +652,7 @@ static int x_run_primal(hank_ctx *ctx) {
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
     // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
     const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
-    const dim3 grd(X.grid), blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e);
+    const dim3 grd(X.grid), blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkf = blk;
     XBackArgs ab{};
     ab.c = c; ab.ss_value = ctx->d_ss_value; ab.xhh = ctx->d_xhh; ab.rho = X.rho; ab.sy = X.sync; ab.st_s = X.st_s;
     ab.err = ctx->d_err; ab.R = ctx->R;
@@ -681,7 +669,7 @@ static int x_run_primal(hank_ctx *ctx) {
         XSweepFwdArgs fa{};
         fa.c = c; fa.R = ctx->R; fa.sy = X.sync + 1; fa.st = X.st_D; fa.D0 = ctx->d_ss_D; fa.groups = 1; fa.Dvirt = X.Dvirt; fa.aggpart = X.aggpart;
         fa.src = X.srcF; fa.units = X.unitsF; fa.all_members = X.neigh ? 0 : 1;
-        x_launch_fwd(X, 0, true, grd, c.n_e, x_lds_fwd(c, 0, true), s, fa);
+        x_launch_fwd(X, 0, true, grd, blkf, x_lds_fwd(c, 1), s, fa);
     }
     HIPC(ctx, hipEventRecord(ctx->ev[2], s));
     hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact * c.n_e, 1, ctx->d_agg);
@@ -724,7 +712,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     const dim3 grd(X.grid);
     // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
     const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
-    const dim3 blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e);
+    const dim3 blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkF = blk;
     XTanBackArgs ab{};
     ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st_ds = X.st_ds;
     ab.src = neigh ? X.srcB : nullptr;
@@ -744,7 +732,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         fa.sy = X.sync + 2 + 2 * p + 1; fa.groups = ps.groups; fa.dpol = w->dpol + ps.dpol_off;
-        x_launch_fwd(X, ps.D, false, grd, c.n_e, x_lds_fwd(c, ps.D, false), s, fa);
+        x_launch_fwd(X, ps.D, false, grd, blkF, x_lds_fwd(c, ps.D), s, fa);
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
         const int W = XG * ps.D;
         hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, W, w->dagg_pass);
@@ -884,7 +872,7 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     if (se && strcmp(se, "xcd") == 0) {
         if (ctx->schedule == 0)
             return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=xcd: n_a=%d needs %d workgroups per XCD (the device has %d) and %zu bytes of LDS per workgroup (it has %zu)", c.n_a,
-                        (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG, std::max(x_lds_primal_back(c), x_lds_fwd(c, 0, true)), (size_t)prop.sharedMemPerBlock);
+                        (c.n_a + XRW - 1) / XRW, prop.multiProcessorCount / XG, std::max(x_lds_primal_back(c), x_lds_fwd(c, 1)), (size_t)prop.sharedMemPerBlock);
         ctx->schedule = 1;
         ctx->forced_xcd = true;
     }
@@ -1023,7 +1011,7 @@ static bool x_tan_fits(const hank_ctx *ctx, int N) {
     const XWork &X = ctx->xw;
     int D = 1;
     while (XG * D < N && D < X.dmax) D *= 2;
-    return std::max(x_lds_tan_back(ctx->c, D), x_lds_fwd(ctx->c, D, true)) <= (size_t)X.lds_max;
+    return std::max(x_lds_tan_back(ctx->c, D), x_lds_fwd(ctx->c, D + 1)) <= (size_t)X.lds_max;
 }
 static bool use_x_jvp(const hank_ctx *ctx, int N) { return (ctx->schedule == 1 || (ctx->schedule == 2 && N <= ctx->xjvp_max)) && x_tan_fits(ctx, N); }
 static bool use_x_fused(const hank_ctx *ctx, int N) { return ctx->schedule == 1 && x_tan_fits(ctx, N); }      // auto: the dual-sweep launches hide the primal chain

@@ -935,37 +935,22 @@ struct XSweepFwdArgs {
     int all_members;            // dev knob: every period waits for every member
 };
 
-// staging of one work unit's source records in LDS (filled by LDS-DMA, 64 lanes per block): lo | w (lwg, or lw as two dword
-// planes) | ig or D_t as two dword planes (where policy partials travel) | the policy partials
-template <int D, bool VAL> struct XStage {
-    static constexpr int OFF_LO = 0;
-    static constexpr int OFF_W = 256;
-    static constexpr int OFF_G = OFF_W + (VAL ? 512 : 1024);
-    static constexpr int OFF_DP = OFF_G + (D > 0 ? 512 : 0);
-    static constexpr int SIZE = OFF_DP + (D == 0 ? 0 : (D == 1 ? 512 : 128 * D * 2 * 2));      // D = 1: two dword planes; D = 2: 1 KB; D = 4: 2 KB
-};
-#define XGLDS(gp, lp, sz) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp), (__attribute__((address_space(3))) void *)(lp), sz, 0, 0)
-
 template <int D, bool VAL, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     constexpr int NSL = D + (VAL ? 1 : 0);              // live slots: the D partials, then the value
     constexpr int SP = XSlots<NSL>::SP, SL = XSlots<NSL>::SL;
     constexpr int IV = D;                               // the value's slot
     constexpr int DD = D > 0 ? D : 1;
-    constexpr bool PIREG = false;                           // the mixing's coefficients in registers
-    typedef XStage<D, VAL> ST;
+    constexpr bool PIREG = NSL < 4;                     // the mixing's coefficients in registers
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const Record &R = A.R;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     double *tile = xl;                                  // [ne][64][SL]
     double *Pish = tile + (size_t)SL * ne * 64;         // [ne*ne] (read when !PIREG)
-    int2 *udsh = reinterpret_cast<int2 *>(Pish + ne * ne + ((ne * ne) & 1));       // [2][32]: the units dealt to the waves, this period's and the next one's
-    char *stage = reinterpret_cast<char *>(udsh + 64);  // [2 n_e][ST::SIZE]: the source records of the period's units
-    int *closh = reinterpret_cast<int *>(stage + (size_t)2 * ne * ST::SIZE);      // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
+    int *closh = reinterpret_cast<int *>(Pish + ne * ne);       // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
     int *srcsh = closh + (size_t)P * ne;                // [P]
     int *ctl = srcsh + P;
-    int *consh = ctl + 8;                               // [16]: column wave w has taken the records of period consh[w] - 1 out of its staging slots
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
@@ -974,7 +959,6 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
     const bool rec = VAL && x == 0;                     // this group writes the record
-    if (threadIdx.x < 16) consh[threadIdx.x] = 0;
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
     for (int k = threadIdx.x; k < P; k += blockDim.x) {
@@ -982,14 +966,9 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         if (A.all_members || (rec && ((w >> 17) & 1))) w = (w & ~0xffff) | ((Sact - 1) << 8);
         srcsh[k] = w;
     }
-    __syncthreads();                                    // (the loader wave reads srcsh before the first group barrier)
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave index in a scalar register: column bases become scalar)
-    // roles: waves 0 .. n_e-1 own a column each; wave n_e polls the group's flags and publishes; the waves behind it are LOADERS:
-    // they stream the next period's source records into LDS (LDS-DMA) while everybody else works on this one
-    const bool syncw = wv >= ne;                        // not a column wave
-    const bool pollw = wv == ne;
-    const int NL = (int)(blockDim.x >> 6) - ne - 1;     // loader waves (>= 1)
-    const int lk = wv - ne - 1;                         // this loader's index (< 0: not a loader)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool syncw = wv >= ne;                        // see k_xtan_back
+    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
     const int e = syncw ? 0 : wv;
     const int r0 = cW * XRW, r = r0 + lane;
     const bool own = !syncw && lane < XRW && r < na;
@@ -1020,7 +999,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     // this lane's own-row record of the period about to be processed (what the aggregate and the record need). At a recorded
     // primal the term dpol_t D_t of the aggregate is taken where the policy partials are loaded anyway — at the SOURCE rows —
     // and a row's own partials only count where the row is clamped (not walked as a source: its partial is zero except on a
-    // knot tie). Branch-free on purpose: these loads are the counted batch behind the period's stores (see XFWD_NLD).
+    // knot tie). Branch-free on purpose: these loads are part of the counted batch behind the period's stores (see XFWD_NLD).
     double polr = 0.0, Dr = 0.0, lwr = 0.0, igr = 0.0, dpr[DD];
 #pragma unroll
     for (int k = 0; k < DD; k++) dpr[k] = 0.0;
@@ -1031,17 +1010,8 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         if constexpr (VAL) { lwr = R.lw[ro]; igr = R.ig[ro]; }
         else { if constexpr (D > 0) Dr = R.Dseq[ro + G]; }      // D_t[r] (row 0 includes what the primal kept on its virtual rows)
     };
-    // The own-row loads of the NEXT period are cold lines of the record (2.4 us from HBM under this load) and vector-memory
-    // waits are in order: behind an ordinary drain (vmcnt(0) before the group barrier) they would cost their whole latency
-    // every period. They are issued AFTER the period's last store, as a batch of exactly XFWD_NLD unconditional instructions,
-    // and the drain waits with vmcnt(XFWD_NLD): everything older than the batch — the stores — has completed, the batch stays
-    // in flight through the publish, the next poll and the next state loads (tests/test_isa_hazards.py counts the instructions
-    // between the two markers in the ISA against the immediate).
-    constexpr int DPI = D == 0 ? 0 : (D <= 2 ? 1 : D / 2);                 // load instructions per row of policy partials
-    constexpr int XFWD_NLD = 1 + DPI + (VAL ? 2 : (D > 0 ? 1 : 0));
     // ---- the two work units of this wave, register sets 0 and 1: per lane a source's lottery record {lo, w, ig D_{t-1} | ig},
-    // its policy partials and (at a recorded primal) D_t of its row — read from the LDS staging the loader wave filled a period
-    // ago — then its state row
+    // its policy partials and (at a recorded primal) D_t of its row; then its state row
     int2 ud[2];                                         // the units' descriptors (wave-uniform)
     int qlo[2];
     double qw[2], qg[2], qdn[2], qdp[2][DD], dd[2][SP];
@@ -1051,48 +1021,21 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         const int2 q = ubase[(size_t)t * Sact * XUCAP + u];
         return make_int2(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y));
     };
-    auto unit_lanes = [&](auto U, int2 d, int i0) {     // which lanes of a unit are sources, which are virtual rows riding on source row 0's record
+    // (branch-free: every lane loads — a lane beyond the unit's sources the unit's last row, an empty unit row 0 of column 0 — and
+    // qon / qvl say what counts)
+    auto load_rec = [&](auto U, int t, int2 d, int i0) {
         constexpr int u = decltype(U)::value;
-        const int cnt = (d.x >> 16) & 0xfff, nv = (d.y >> 16) & 0xff;
+        const int ue = d.x & 15, ja = (d.x >> 4) & 0xfff, cnt = (d.x >> 16) & 0xfff, nv = (d.y >> 16) & 0xff;
         const int i = i0 + lane;
-        qvl[u] = i >= cnt && i < cnt + nv;
-        qon[u] = i < cnt + nv;
-    };
-    auto read_rec = [&](auto U, int s) {                // from the staging of unit slot s
-        constexpr int u = decltype(U)::value;
-        const char *sb = stage + (size_t)s * ST::SIZE;
-        qlo[u] = reinterpret_cast<const int *>(sb + ST::OFF_LO)[lane];
-        qdn[u] = 0.0; qg[u] = 0.0;
-        if constexpr (VAL) {
-            const int *wp = reinterpret_cast<const int *>(sb + ST::OFF_W);
-            qw[u] = __hiloint2double(wp[64 + lane], wp[lane]);
-            if constexpr (D > 0) { const int *gp = reinterpret_cast<const int *>(sb + ST::OFF_G); qg[u] = __hiloint2double(gp[64 + lane], gp[lane]); }
-        } else {
-            const double2 wg = reinterpret_cast<const double2 *>(sb + ST::OFF_W)[lane];
-            qw[u] = wg.x; qg[u] = wg.y;
-            if constexpr (D > 0) { const int *gp = reinterpret_cast<const int *>(sb + ST::OFF_G); qdn[u] = __hiloint2double(gp[64 + lane], gp[lane]); }
-        }
-        if constexpr (D == 1) { const int *dp = reinterpret_cast<const int *>(sb + ST::OFF_DP); qdp[u][0] = __hiloint2double(dp[64 + lane], dp[lane]); }
-        if constexpr (D >= 2) {
-#pragma unroll
-            for (int k = 0; k < D / 2; k++) { const double2 q = reinterpret_cast<const double2 *>(sb + ST::OFF_DP + 1024 * k)[lane]; qdp[u][2 * k] = q.x; qdp[u][2 * k + 1] = q.y; }
-        }
-    };
-    auto load_rec = [&](auto U, int t, int2 d, int i0) {        // straight from memory (the rare units beyond the staged ones)
-        constexpr int u = decltype(U)::value;
-        const int ue = d.x & 15, ja = (d.x >> 4) & 0xfff, cnt = (d.x >> 16) & 0xfff;
-        const int i = i0 + lane;
+        const bool real = i < cnt;
+        qvl[u] = !real && i < cnt + nv;                 // a member's virtual row riding on source row 0's record
+        qon[u] = real || qvl[u];
         const size_t cb = (size_t)t * G + (size_t)ue * na;
-        const int j = i < cnt ? ja + i : 0;
-        qlo[u] = 0; qw[u] = 0.0; qg[u] = 0.0; qdn[u] = 0.0;
-#pragma unroll
-        for (int k = 0; k < DD; k++) qdp[u][k] = 0.0;
-        if (qon[u]) {
-            qlo[u] = R.lo[cb + j];
-            if constexpr (VAL) { qw[u] = R.lw[cb + j]; if constexpr (D > 0) qg[u] = R.ig[cb + j]; }
-            else { const double2 wg = R.lwg[cb + j]; qw[u] = wg.x; qg[u] = wg.y; if constexpr (D > 0) qdn[u] = R.Dseq[cb + G + j]; }
-            if constexpr (D > 0) xload_row_plain<DD>(A.dpol + (((size_t)t * A.groups + x) * G + (size_t)ue * na + j) * D, qdp[u]);
-        }
+        const int j = real ? ja + i : (qvl[u] ? 0 : min(ja + max(cnt - 1, 0), na - 1));
+        qlo[u] = R.lo[cb + j];
+        if constexpr (VAL) { qw[u] = R.lw[cb + j]; if constexpr (D > 0) qg[u] = R.ig[cb + j]; }       // (ig only weights the policy partials)
+        else { const double2 wg = R.lwg[cb + j]; qw[u] = wg.x; qg[u] = wg.y; if constexpr (D > 0) qdn[u] = R.Dseq[cb + G + j]; }
+        if constexpr (D > 0) xload_row_plain<DD>(A.dpol + (((size_t)t * A.groups + x) * G + (size_t)ue * na + j) * D, qdp[u]);
     };
     auto load_state = [&](auto U, size_t hb, int2 d, int i0) {
         constexpr int u = decltype(U)::value;
@@ -1105,52 +1048,41 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     };
     const std::integral_constant<int, 0> I0;
     const std::integral_constant<int, 1> I1;
-    // ---- the loader waves: LDS-DMA of the source records of the next period's staged units (lane = source; a virtual lane loads
-    // source row 0's record), requested as soon as the column waves have taken this period's records out of the staging: the
-    // HBM latency of these cold lines (2.4 us under this load) passes behind the whole period, on waves that have nothing else
-    // to wait for — vector-memory waits are in order, a column wave would pay it at its next wait, and one wave alone needs
-    // ~100 clocks per DMA instruction: the units are dealt to NL loaders. A loader drains its DMAs (vmcnt(0)) before the
-    // barrier that hands the staging to the readers.
-    int2 dsc = make_int2(0, 0);                         // lane s: the descriptor of unit s of the period to stage next
-    auto request_descs = [&](int t) {
-        const int nu = t < P ? min((srcsh[min(t, P - 1)] >> 18) & 0xff, 2 * ne) : 0;
-        dsc = make_int2(0, 0);
-        if (lane < nu) dsc = ubase[(size_t)t * Sact * XUCAP + lane];
+    int2 udn[2];                                        // the descriptors of the period after next, on their way (loaded a period ahead: cold lines)
+    bool udv[2] = {false, false};                       // ... and whether this wave has such a unit at all
+    udn[0] = udn[1] = make_int2(0, 0);
+    auto request_units = [&](int t) {                   // this wave's two units of period t (branch-free: an index that exists is loaded anyway)
+        const int tc = min(t, P - 1);
+        int nu = (srcsh[tc] >> 18) & 0xff;
+        nu = t < P ? nu : 0;
+        udv[0] = wv < nu; udv[1] = wv + ne < nu;
+        udn[0] = ubase[(size_t)tc * Sact * XUCAP + (udv[0] ? wv : 0)];
+        udn[1] = ubase[(size_t)tc * Sact * XUCAP + (udv[1] ? wv + ne : 0)];
     };
-    auto stage_period = [&](int t) {                    // t < P; dsc holds its descriptors
-        if (lk == 0 && lane < 32) udsh[(t & 1) * 32 + lane] = dsc;
-        const int nu = min((srcsh[t] >> 18) & 0xff, 2 * ne);
-        for (int s2 = lk; s2 < nu; s2 += NL) {
-            // (slot s2 belongs to column wave s2 mod n_e: it has taken the previous period's records out)
-            while (reinterpret_cast<volatile int *>(consh)[s2 >= ne ? s2 - ne : s2] < t) __builtin_amdgcn_s_sleep(1);
-            const int dx = __builtin_amdgcn_readlane(dsc.x, s2), dy = __builtin_amdgcn_readlane(dsc.y, s2);
-            const int ue = dx & 15, ja = (dx >> 4) & 0xfff, cnt = (dx >> 16) & 0xfff, nv = (dy >> 16) & 0xff;
-            const size_t cb = (size_t)t * G + (size_t)ue * na;
-            const int j = lane < cnt ? ja + lane : 0;
-            char *sb = stage + (size_t)s2 * ST::SIZE;
-            if (lane < cnt + nv) {
-                XGLDS(R.lo + cb + j, sb + ST::OFF_LO, 4);
-                if constexpr (VAL) {
-                    const int *wp = reinterpret_cast<const int *>(R.lw + cb + j);
-                    XGLDS(wp, sb + ST::OFF_W, 4); XGLDS(wp + 1, sb + ST::OFF_W + 256, 4);
-                    if constexpr (D > 0) { const int *gp = reinterpret_cast<const int *>(R.ig + cb + j); XGLDS(gp, sb + ST::OFF_G, 4); XGLDS(gp + 1, sb + ST::OFF_G + 256, 4); }
-                } else {
-                    XGLDS(R.lwg + cb + j, sb + ST::OFF_W, 16);
-                    if constexpr (D > 0) { const int *gp = reinterpret_cast<const int *>(R.Dseq + cb + G + j); XGLDS(gp, sb + ST::OFF_G, 4); XGLDS(gp + 1, sb + ST::OFF_G + 256, 4); }
-                }
-                if constexpr (D > 0) {
-                    const double *dp = A.dpol + (((size_t)t * A.groups + x) * G + (size_t)ue * na + j) * D;
-                    if constexpr (D == 1) { XGLDS(reinterpret_cast<const int *>(dp), sb + ST::OFF_DP, 4); XGLDS(reinterpret_cast<const int *>(dp) + 1, sb + ST::OFF_DP + 256, 4); }
-                    if constexpr (D >= 2) XGLDS(dp, sb + ST::OFF_DP, 16);
-                    if constexpr (D >= 4) XGLDS(dp + 2, sb + ST::OFF_DP + 1024, 16);
-                }
-            }
-        }
+    auto take_units = [&]() {
+        ud[0] = udv[0] ? make_int2(__builtin_amdgcn_readfirstlane(udn[0].x), __builtin_amdgcn_readfirstlane(udn[0].y)) : make_int2(0, 0);
+        ud[1] = udv[1] ? make_int2(__builtin_amdgcn_readfirstlane(udn[1].x), __builtin_amdgcn_readfirstlane(udn[1].y)) : make_int2(0, 0);
     };
-    if (lk >= 0) { request_descs(0); stage_period(0); request_descs(1); }
-    if (!syncw) prefetch(0);
-    xbar_arrive(true);                                  // the initial state has reached L2 (and period 0's staging has landed): episode 1
-    if (pollw) xpublish(A.sy, x, cW, 1u);
+    // The loads of the NEXT period — its two units' records, the own-row record, the descriptors of the period after — are cold
+    // lines of the record (2.4 us from HBM under this load) and vector-memory waits are in order: behind an ordinary drain
+    // (vmcnt(0) before the group barrier) they cost their whole latency every period. They are therefore issued AFTER the
+    // period's last store, as a batch of exactly XFWD_NLD instructions, every one of them unconditional, and the drain waits
+    // with vmcnt(XFWD_NLD): everything older than the batch — the stores — has completed, the batch itself stays in flight
+    // through the publish, the next poll and the next state loads (tests/test_isa_hazards.py counts the instructions between
+    // the two markers in the ISA against the immediate).
+    constexpr int DPI = D == 0 ? 0 : (D <= 2 ? 1 : D / 2);                 // load instructions per row of policy partials
+    constexpr int XFWD_NLD = 2 * (1 + (VAL ? (D > 0 ? 2 : 1) : 1 + (D > 0 ? 1 : 0)) + DPI) + (1 + DPI + (VAL ? 2 : (D > 0 ? 1 : 0))) + 2;
+    auto next_period_loads = [&](int t) {               // t: the period that has just been stored (ud holds the NEXT period's units by now)
+        const int t1 = min(t + 1, P - 1);
+        load_rec(I0, t1, ud[0], 0);
+        load_rec(I1, t1, ud[1], 0);
+        prefetch(t1);
+        request_units(t + 2);
+    };
+    xbar_arrive(!syncw);                                // the initial state has reached L2: episode 1
+    if (sync_duty) xpublish(A.sy, x, cW, 1u);
+    ud[0] = ud[1] = make_int2(0, 0);
+    if (!syncw) { request_units(0); take_units(); load_rec(I0, 0, ud[0], 0); load_rec(I1, 0, ud[1], 0); prefetch(0); request_units(1); }
     int cur = 0;
     bool vnz = false;                                   // the virtual rows may hold mass: some column was clamped last period
     const int son = (x == 0 && cW < 32) ? cW : -1;     // dev stamps (make stamp)
@@ -1166,35 +1098,22 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
             double z[SL];
 #pragma unroll
             for (int k = 0; k < SL; k++) z[k] = 0.0;
-            xtile_store<SL>(myt, z);                    // (every wave is past the previous period's mixing: the end-of-period barrier)
+            xtile_store<SL>(myt, z);                    // (every wave is past the previous period's mixing: xbar_arrive)
         }
-        if (pollw) xpoll(A.sy, x, sw & 255, (sw >> 8) & 255, (unsigned)(t + 1));   // this period's source members have published period t-1
-        if (lk >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this period's staging has landed
+        if (sync_duty) xpoll(A.sy, x, sw & 255, (sw >> 8) & 255, (unsigned)(t + 1));   // this period's source members have published period t-1
         xlds_barrier();
         XSTAMP(1, son, t, 1);
-        if (lk >= 0 && t + 1 < P) { stage_period(t + 1); request_descs(t + 2); }
         double pagg[DD];
 #pragma unroll
         for (int k = 0; k < DD; k++) pagg[k] = 0.0;
         double v0 = 0.0;                                // the record's row 0: the mass on every member's virtual row of this column
-        const bool need0 = !syncw && rec && r0 == 0 && vnz && clo == 0;      // (wave-uniform)
         if (!syncw) {
+            const bool need0 = rec && r0 == 0 && vnz && clo == 0;      // (wave-uniform)
             if constexpr (VAL) {
                 if (need0 && lane < Sact) v0 = rows.load_one(hb + gx + ((size_t)e * Sact + lane) * 64 + 63, IV);
             }
-            const int2 q0 = udsh[(t & 1) * 32 + wv], q1 = udsh[(t & 1) * 32 + wv + ne];
-            ud[0] = make_int2(__builtin_amdgcn_readfirstlane(q0.x), __builtin_amdgcn_readfirstlane(q0.y));
-            ud[1] = make_int2(__builtin_amdgcn_readfirstlane(q1.x), __builtin_amdgcn_readfirstlane(q1.y));
-            unit_lanes(I0, ud[0], 0);
-            unit_lanes(I1, ud[1], 0);
             load_state(I0, hb, ud[0], 0);
             load_state(I1, hb, ud[1], 0);
-            // the column waves take their two units' records out of the staging at once (LDS -> registers) and say so: the loaders
-            // refill a wave's two slots for the next period as soon as it has, a whole period ahead
-            read_rec(I0, wv);
-            read_rec(I1, wv + ne);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) reinterpret_cast<volatile int *>(consh)[wv] = t + 1;
             // Young lottery of a source (ForwardIteration.jl:59-73): (1-w) to row lo, w to row lo+1; the weight's partial is
             // dpol / gap (zero where clamped), times D_{t-1} of the row. Only the parts that land in the unit's own target run
             // [ta, tb) are added (the other part of a seam source belongs to the neighbouring unit).
@@ -1235,13 +1154,13 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
                 const int2 d = u2 < 2 * ne ? ud[u2 >= ne ? 1 : 0] : unit_desc(t, u2);
                 const int tot = ((d.x >> 16) & 0xfff) + ((d.y >> 16) & 0xff);
                 for (int i0 = u2 < 2 * ne ? 64 : 0; i0 < tot; i0 += 64) {
-                    unit_lanes(I0, d, i0);
                     load_rec(I0, t, d, i0);
                     load_state(I0, hb, d, i0);
                     process(I0, d);
                 }
             }
             if constexpr (VAL) { if (need0) v0 = xwave_sum(v0); }
+            take_units();                               // the next period's descriptors (requested a period ago; this wave's loads have all landed here)
             XSTAMP(1, son, t, 2);
             // the mass point: sources clamped at the first grid point (:54-58) go to row 0 with weight one and no weight
             // partial. Each member sums ITS clamped rows into its virtual row (never combined: everything downstream is
@@ -1257,7 +1176,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         }
         XSTAMP(1, son, t, 3);
         XSTAMPV(1, son, t);
-        if (pollw) xpoll(A.sy, x, 0, Sact - 1, (unsigned)(t + 1));      // EVERY member is done reading the half about to be overwritten
+        if (sync_duty) xpoll(A.sy, x, 0, Sact - 1, (unsigned)(t + 1));      // EVERY member is done reading the half about to be overwritten
         xlds_barrier();
         XSTAMP(1, son, t, 4);
         vnz = ((sw >> 16) & 1) != 0;
@@ -1308,11 +1227,11 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         XSTAMP(1, son, t, 5);
         if (!syncw) {
             asm volatile("; XFWD_BATCH_BEGIN" ::: "memory");
-            prefetch(min(t + 1, P - 1));
+            next_period_loads(t);
             asm volatile("; XFWD_BATCH_END\n\ts_waitcnt vmcnt(%0)" ::"n"(XFWD_NLD) : "memory");       // this member's stores have reached L2 ...
         }
         xlds_barrier();
-        if (pollw) xpublish(A.sy, x, cW, (unsigned)(t + 2));                                            // ... episode t+2
+        if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(t + 2));                                       // ... episode t+2
         XSTAMP(1, son, t, 6);
     }
 }
