@@ -47,8 +47,10 @@ enum {
     HANK_ERR_NONMONOTONE = 6, /* savings policy not monotone in wealth (cannot happen when the
                                  knots check passes; guards the segmented Young push-forward)      */
     HANK_ERR_NOMEM = 7,
-    HANK_ERR_SWEEP = 8,       /* a persistent sweep could not form its workgroup groups or a wait in it timed out
-                                 (host-pointer entries fall back to the per-period launches by themselves)     */
+    HANK_ERR_SWEEP = 8,       /* a persistent sweep could not form its workgroup groups or a wait in it timed out (every wait
+                                 is bounded in time: 20 ms, HANK_XWAIT_MS at hank_create; the message says how long it
+                                 waited); host-pointer entries fall back to the per-period launches by themselves. The
+                                 persistent sweeps assume the process has the GPU to itself          */
     HANK_ERR_LAUNCH = 9       /* a kernel launch / graph / copy was refused by the HIP runtime (the message names it)   */
 };
 
@@ -111,7 +113,8 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out);
 
 /* Same, with DEVICE pointers (inputs already resident in HBM); enqueued on the context's stream,
  * asynchronous: call hank_sync (or synchronise the stream) before reading the outputs.
- * hank_primal_dev reports device-side errors (knots/domain) at the next hank_check. */
+ * hank_primal_dev reports device-side errors (knots/domain) at the next hank_check. Device pointers must belong to the
+ * context's device (hank_create_on); they are not validated. */
 int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out);
 int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_out);
 int hank_check(hank_ctx *ctx); /* sync + fetch the device error word of the last primal          */
@@ -120,7 +123,13 @@ int hank_check(hank_ctx *ctx); /* sync + fetch the device error word of the last
  * recomputes the primal (NewtonRaphson.jl:95; GeneralStructures.jl:546-547), so value and N partials
  * travel together. One call = hank_primal + hank_jvp, but both recurrences advance in ONE chain of
  * T launches per direction (the tangent sweep runs one period behind the primal sweep inside the same
- * launches) instead of two. Leaves the context exactly as hank_primal followed by hank_jvp would.    */
+ * launches) instead of two. Leaves the context exactly as hank_primal followed by hank_jvp would.
+ * PRIMAL MEMO (host-pointer form only): y_Iteration calls JVP(fullFunction, x, y) about 21 times per Newton step at ONE x
+ * (NewtonRaphson.jl:91-95). When `xhh` and the boundary are bit-identical to the ones whose linearisation is on record,
+ * hank_primal_jvp runs the tangent sweeps alone (= hank_jvp) and returns the recorded value: results equal the un-memoised
+ * call's bit for bit under one implementation (HANK_SCHEDULE=launch|xcd) and to the rounding of the aggregate sums (1e-13)
+ * in the default schedule, where a recorded primal is served by the persistent tangent sweeps. HANK_PRIMAL_MEMO=0 (read at
+ * hank_create) switches it off; hank_stats out[6] counts the skipped primal sweeps. The _dev form never skips work.        */
 int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_t N, double *agg_out,
                     double *dagg_out);
 int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh, int32_t N,
@@ -184,7 +193,9 @@ int hank_stationary_dist(hank_ctx *ctx, const double *policy, double *D_io, doub
  * the recursion J̅[s,t] = J̅[s-1,t-1] + helper (:363-371). Here: ONE backward tangent sweep of n_hh directions (unit shock to
  * household input k in the last period: the policy response at every lag), one single-period forward push of all P*n_hh lagged
  * responses (the lottery impulse), P-1 steps of the transposed forward step (the expectation vectors), one product.
- * Requires hank_primal at the constant steady-state path with the steady state as both boundaries.
+ * Requires hank_primal (host-pointer form) at the constant steady-state path with the steady state as both boundaries; anything
+ * else is refused with HANK_ERR_NOT_READY (a path that varies over time, a device-pointer primal, or a recorded policy whose
+ * first and last period differ by more than 1e-6 of its scale).
  *   F_out  (P, P, n_hh) column-major: F[u, j, k] = effect on the aggregate, u periods after the policy moved, of the policy
  *          response with j periods to go before a unit shock to input k (the reference's helper; "fake news" matrix)
  *   Dv_out (P, n_hh): Dv[j, k] = the direct term, (policy response at lag j) . D_ss
@@ -204,7 +215,8 @@ int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]);
  * workspaces allocated (a change of batch width N re-uses a cached workspace: a small most-recently-used cache, 3 deep),
  * out[2] hipGraphs captured (per-period schedule), out[3] schedule in use (1 = XCD-local persistent sweeps, 0 = one
  * launch per period), out[4] times this context fell back from 1 to 0, out[5] device-resident value-function iterations
- * run by hank_vfi; the rest reserved. */
+ * run by hank_vfi, out[6] primal sweeps the memo of hank_primal_jvp skipped, out[7] primal sweeps run (hank_primal[_dev],
+ * hank_primal_jvp[_dev]). */
 int hank_stats(hank_ctx *ctx, int64_t out[8]);
 
 #ifdef __cplusplus

@@ -125,6 +125,13 @@ struct hank_ctx {
     struct { double *dpT = nullptr, *iota = nullptr, *E = nullptr, *Cp = nullptr, *F = nullptr, *Dv = nullptr; int N = 0; } fn;   // hank_fake_news workspace
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // see hank_stats
+    // primal memo of the host-pointer hank_primal_jvp (NewtonRaphson.jl:91-95 calls JVP(fullFunction, x, y) ~21 times at one x):
+    // the x whose linearisation is on record, as the host handed it in
+    bool memo_on = true;                              // HANK_PRIMAL_MEMO=0 (read at hank_create) switches it off
+    bool memo_valid = false;
+    std::vector<double> memo_xhh;
+    bool stationary = false;                          // the recorded primal is the constant steady-state path with the steady state as both boundaries (hank_fake_news)
+    std::vector<double> h_ss_value, h_ss_D;           // the boundary as the host handed it in (stationarity check)
     hipEvent_t ev_stream = nullptr;
     char errmsg[512] = {0};
 };
@@ -165,14 +172,19 @@ static int hip_status(hipError_t e) {
 // context per GPU of a node (GeneralStructures.jl:542-550 has no notion of a device: the shim owns the placement).
 struct DeviceGuard {
     int prev = -1;
-    bool switched = false;
+    bool switched = false, ok = true;
     explicit DeviceGuard(const hank_ctx *ctx);
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 DeviceGuard::DeviceGuard(const hank_ctx *ctx) {
-    if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    if (!ctx) return;
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != ctx->device) { switched = hipSetDevice(ctx->device) == hipSuccess; ok = switched; }
 }
-#define ENTER(ctx) DeviceGuard dev_guard_(ctx)
+// (a call must never run on the caller's device with another device's pointers: a failed switch fails the call)
+#define ENTER(ctx)                                                                                                       \
+    DeviceGuard dev_guard_(ctx);                                                                                         \
+    if (!dev_guard_.ok) return fail(ctx, HANK_ERR_NO_DEVICE, "HIP device %d of this context could not be made current", (ctx) ? (ctx)->device : -1)
 
 template <typename T>
 static hipError_t dmalloc(T **p, size_t count) {
@@ -521,10 +533,16 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.unit_overflow, 1));
     HIPC(ctx, hipMemset(X.unit_overflow, 0, sizeof(int)));
     if (const char *ng = getenv("HANK_XNEIGH")) X.neigh = atoi(ng) != 0;
+    {   // the bound on every wait inside a persistent sweep, in 100 MHz ticks (read once, here)
+        double ms = 20.0;
+        if (const char *wm = getenv("HANK_XWAIT_MS")) ms = atof(wm);
+        const unsigned long long ticks = (unsigned long long)(std::max(ms, 0.01) * 1e5);
+        HIPC(ctx, hipMemcpyToSymbol(HIP_SYMBOL(hank::g_xwait_ticks), &ticks, sizeof(ticks)));
+    }
     if (const char *sv = getenv("HANK_XSYNCWAVE")) X.syncwave = atoi(sv) != 0;
     X.lds_max = (int)prop.sharedMemPerBlock;
     if (const char *xf = getenv("HANK_XFAULT")) {      // "placement" | "timeout", optionally ":primal" | ":tangent" | ":fixedpoint" (default: every persistent launch)
-        X.fault = strncmp(xf, "placement", 9) == 0 ? XERR_PLACEMENT : (strncmp(xf, "timeout", 7) == 0 ? XERR_TIMEOUT : 0);
+        X.fault = strncmp(xf, "placement", 9) == 0 ? XERR_PLACEMENT : (strncmp(xf, "timeout", 7) == 0 ? XERR_TIMEOUT : (strncmp(xf, "stall", 5) == 0 ? 3 : 0));
         const char *w = strchr(xf, ':');
         X.fault_where = !w ? 7 : (strcmp(w, ":primal") == 0 ? 1 : (strcmp(w, ":tangent") == 0 ? 2 : (strcmp(w, ":fixedpoint") == 0 ? 4 : 7)));
     }
@@ -633,13 +651,14 @@ static int x_serialize_end(hank_ctx *ctx) {
 // zero the sync blocks of the launches about to be enqueued (and, under the dev knob, pre-set their status words)
 static int x_sync_reset(hank_ctx *ctx, XSync *base, int count, int where) {     // where: 1 primal sweeps, 2 tangent sweeps, 4 the steady state's fixed points
     HIPC(ctx, hipMemsetAsync(base, 0, sizeof(XSync) * (size_t)count, ctx->stream));
-    if (ctx->xw.fault && (ctx->xw.fault_where & where)) hipLaunchKernelGGL(k_xpoison, dim3(1), dim3(64), 0, ctx->stream, base, count, (unsigned)ctx->xw.fault);
+    if (ctx->xw.fault && ctx->xw.fault != 3 && (ctx->xw.fault_where & where)) hipLaunchKernelGGL(k_xpoison, dim3(1), dim3(64), 0, ctx->stream, base, count, (unsigned)ctx->xw.fault);
     return HANK_OK;
 }
 
 // the Float64 recurrences at the context's current x (d_xhh) and boundary: two persistent launches on ONE XCD's
 // workgroups (the policy sequence, the distribution path and the linearisation record the tangent sweeps read)
-static int x_run_primal(hank_ctx *ctx) {
+// skip_fwd: the distribution sweep travels with the tangents' forward sweep instead (k_xfwd<D, true>, x_run_tangent(.., val))
+static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false) {
     XWork &X = ctx->xw;
     const Consts &c = ctx->c;
     const size_t P = c.P;
@@ -665,22 +684,24 @@ static int x_run_primal(hank_ctx *ctx) {
     X.rng_valid = false;
     x_ensure_rng(ctx);
     HIPC(ctx, hipEventRecord(ctx->ev[6], s));
-    {
+    if (!skip_fwd) {
         XSweepFwdArgs fa{};
         fa.c = c; fa.R = ctx->R; fa.sy = X.sync + 1; fa.st = X.st_D; fa.D0 = ctx->d_ss_D; fa.groups = 1; fa.Dvirt = X.Dvirt; fa.aggpart = X.aggpart;
         fa.src = X.srcF; fa.units = X.unitsF; fa.all_members = X.neigh ? 0 : 1;
         x_launch_fwd(X, 0, true, grd, blkf, x_lds_fwd(c, 1), s, fa);
     }
     HIPC(ctx, hipEventRecord(ctx->ev[2], s));
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact * c.n_e, 1, ctx->d_agg);
-    hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
+    if (!skip_fwd) {
+        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact * c.n_e, 1, ctx->d_agg);
+        hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
+    }
     HIPC(ctx, hipGetLastError());
     rc = x_serialize_end(ctx);
     if (rc) return rc;
-    ctx->stats[0] += 2;
+    ctx->stats[0] += skip_fwd ? 1 : 2;
     X.last_passes = 1;
     ctx->launches[0] = ctx->launches[1] = 1;
-    ctx->ev_valid[0] = ctx->ev_valid[1] = true;
+    ctx->ev_valid[0] = true; ctx->ev_valid[1] = !skip_fwd;
     ctx->ev_valid[2] = ctx->ev_valid[3] = ctx->ev_valid[4] = ctx->ev_valid[5] = false;
     ctx->primal_done = true;
     X.src_valid = false;
@@ -690,7 +711,8 @@ static int x_run_primal(hank_ctx *ctx) {
 }
 
 // the N partials of `w` at the recorded primal: two persistent launches per pass of up to 8*dmax directions, every XCD a group
-static int x_run_tangent(hank_ctx *ctx, XTan *w) {
+// val: the first pass's forward sweep carries the value too (the Float64 distribution sweep of a Dual pass) and writes the record
+static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false) {
     XWork &X = ctx->xw;
     const Consts &c = ctx->c;
     const size_t P = c.P;
@@ -716,6 +738,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     XTanBackArgs ab{};
     ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st_ds = X.st_ds;
     ab.src = neigh ? X.srcB : nullptr;
+    ab.stall = X.fault == 3 ? 1 : 0;
     XSweepFwdArgs fa{};
     fa.c = c; fa.R = ctx->R; fa.st = X.st_dD; fa.daggpart = w->daggpart; fa.src = X.srcF; fa.units = X.unitsF; fa.all_members = neigh ? 0 : 1;
     HIPC(ctx, hipEventRecord(ctx->ev[3], s));
@@ -732,7 +755,13 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w) {
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         fa.sy = X.sync + 2 + 2 * p + 1; fa.groups = ps.groups; fa.dpol = w->dpol + ps.dpol_off;
-        x_launch_fwd(X, ps.D, false, grd, blkF, x_lds_fwd(c, ps.D), s, fa);
+        const bool v = val && p == 0;
+        if (v) { fa.D0 = ctx->d_ss_D; fa.Dvirt = X.Dvirt; fa.aggpart = X.aggpart; }
+        x_launch_fwd(X, ps.D, v, grd, blkF, x_lds_fwd(c, ps.D + (v ? 1 : 0)), s, fa);
+        if (v) {
+            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact * c.n_e, 1, ctx->d_agg);
+            hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
+        }
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
         const int W = XG * ps.D;
         hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, W, w->dagg_pass);
@@ -773,8 +802,10 @@ static int x_status(hank_ctx *ctx) {
         if (h[k].status[0] != 0) {
             ctx->primal_done = false;
             for (XTan &t : X.tans) t.valid = false;
-            return fail(ctx, HANK_ERR_SWEEP, "persistent %s sweep %zu (0 = primal, then one per tangent pass): %s on XCD %u (workgroups per XCD: %u %u %u %u %u %u %u %u)",
-                        (k & 1) ? "forward" : "backward", k / 2, h[k].status[0] == XERR_PLACEMENT ? "a group is short of members" : "a wait timed out",
+            char waited[64] = "";
+            if (h[k].status[0] == XERR_TIMEOUT) snprintf(waited, sizeof(waited), " after %.1f ms", h[k].status[2] / 1000.0);
+            return fail(ctx, HANK_ERR_SWEEP, "persistent %s sweep %zu (0 = primal, then one per tangent pass): %s%s on XCD %u (workgroups per XCD: %u %u %u %u %u %u %u %u)",
+                        (k & 1) ? "forward" : "backward", k / 2, h[k].status[0] == XERR_PLACEMENT ? "a group is short of members" : "a wait timed out", waited,
                         h[k].status[1], h[k].ticket[0][0], h[k].ticket[1][0], h[k].ticket[2][0], h[k].ticket[3][0], h[k].ticket[4][0],
                         h[k].ticket[5][0], h[k].ticket[6][0], h[k].ticket[7][0]);
         }
@@ -877,6 +908,7 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
         ctx->forced_xcd = true;
     }
     if (const char *xm = getenv("HANK_XJVP_MAX")) ctx->xjvp_max = atoi(xm);
+    if (const char *pm = getenv("HANK_PRIMAL_MEMO")) ctx->memo_on = atoi(pm) != 0;
     int rc = HANK_OK;
     if (ctx->schedule == 0) rc = build_primal_graphs(ctx);
     else rc = x_setup(ctx);
@@ -938,15 +970,38 @@ int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *s
     ENTER(ctx);
     if (!ctx || !ss_end_value || !ss_init_D) return fail(ctx, HANK_ERR_BAD_ARG, "null boundary pointer");
     const size_t G = ctx->c.G;
+    // the same boundary again (the reference's closures pass ss_end / ss_initial on every call, NewtonRaphson.jl:78-79): nothing
+    // to do, and the recorded primal stays valid
+    if (ctx->boundary_set && ctx->h_ss_value.size() == G && ctx->h_ss_D.size() == G &&
+        memcmp(ctx->h_ss_value.data(), ss_end_value, sizeof(double) * G) == 0 && memcmp(ctx->h_ss_D.data(), ss_init_D, sizeof(double) * G) == 0) {
+        ctx->errmsg[0] = 0;
+        return HANK_OK;
+    }
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(ctx->d_ss_value, ss_end_value, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
     HIPC(ctx, hipMemcpyAsync(ctx->d_ss_D, ss_init_D, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     ctx->boundary_set = true;
     ctx->primal_done = false;
+    ctx->memo_valid = false;
+    ctx->stationary = false;
+    ctx->h_ss_value.assign(ss_end_value, ss_end_value + G);
+    ctx->h_ss_D.assign(ss_init_D, ss_init_D + G);
     for (TanWork &t : ctx->tws) t.valid = false;
     ctx->errmsg[0] = 0;
     return HANK_OK;
+}
+
+// which x the record belongs to: the host-pointer entries know it (and whether it is a constant path), the device-pointer
+// entries do not
+static void note_primal_x(hank_ctx *ctx, const double *xhh) {
+    const size_t n = (size_t)ctx->c.n_hh * ctx->c.P, nh = ctx->c.n_hh;
+    if (!xhh) { ctx->memo_valid = false; ctx->stationary = false; return; }
+    ctx->memo_xhh.assign(xhh, xhh + n);
+    ctx->memo_valid = true;
+    bool constant = true;
+    for (size_t k = nh; k < n && constant; k++) constant = xhh[k] == xhh[k - nh];
+    ctx->stationary = constant;      // (hank_fake_news also compares the first and the last recorded policy on the device)
 }
 
 static int run_primal(hank_ctx *ctx, double *d_agg_out) {
@@ -994,11 +1049,11 @@ static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcp
     const size_t P = ctx->c.P;
     if (xhh) {
         HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, kind, ctx->stream));
-        rc = x_run_primal(ctx);
+        rc = x_run_primal(ctx, true);        // the distribution sweep rides on the tangents' forward sweep (value + partials)
         if (rc) return rc;
     }
     HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
-    rc = x_run_tangent(ctx, w);
+    rc = x_run_tangent(ctx, w, xhh != nullptr);
     if (rc) return rc;
     if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, w->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1030,6 +1085,8 @@ int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
     ENTER(ctx);
     if (!ctx || !d_xhh) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    note_primal_x(ctx, nullptr);
+    ctx->stats[7]++;
     if (use_x_primal(ctx)) return x_primal(ctx, d_xhh, hipMemcpyDeviceToDevice, d_agg_out);
     const size_t P = ctx->c.P;
     HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, d_xhh, sizeof(double) * ctx->c.n_hh * P, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1049,6 +1106,7 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
     const size_t P = ctx->c.P;
     for (size_t t = 0; t < P; t++)
         if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
+    note_primal_x(ctx, nullptr);
     int rc = HANK_OK;
     bool done = false;
     if (use_x_primal(ctx)) {
@@ -1071,6 +1129,8 @@ int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {
         HIPC(ctx, hipMemcpyAsync(agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
         HIPC(ctx, hipStreamSynchronize(ctx->stream));
     }
+    note_primal_x(ctx, xhh);
+    ctx->stats[7]++;
     ctx->errmsg[0] = 0;
     return HANK_OK;
 }
@@ -1174,6 +1234,8 @@ int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh
     ENTER(ctx);
     if (!ctx || !d_xhh || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    note_primal_x(ctx, nullptr);      // (this entry never skips work: bench.py times it)
+    ctx->stats[7]++;
     if (use_x_fused(ctx, N)) return x_dual(ctx, d_xhh, d_dxhh, hipMemcpyDeviceToDevice, N, d_agg_out, d_dagg_out);
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
@@ -1196,6 +1258,22 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
     for (size_t t = 0; t < P; t++)
         if (!(1.0 + xhh[ctx->c.n_hh * t] > 0.0)) return fail(ctx, HANK_ERR_DOMAIN, "1 + r must be positive (period %zu)", t + 1);
     int rc = HANK_OK;
+    // The reference calls JVP(fullFunction, x, y) about 21 times per Newton step at ONE x (NewtonRaphson.jl:91-95) and its Dual
+    // pass recomputes the primal every time (GeneralStructures.jl:546-547). The linearisation of the x on record is still
+    // valid when the same x comes in again: only the tangent sweeps run (what hank_jvp does), the value is the recorded one.
+    if (ctx->memo_on && ctx->primal_done && ctx->memo_valid && ctx->memo_xhh.size() == (size_t)ctx->c.n_hh * P &&
+        memcmp(ctx->memo_xhh.data(), xhh, sizeof(double) * ctx->c.n_hh * P) == 0) {
+        ctx->stats[6]++;
+        rc = hank_jvp(ctx, dxhh, N, dagg_out);
+        if (rc) return rc;
+        if (agg_out) {
+            HIPC(ctx, join_side(ctx));
+            HIPC(ctx, hipMemcpyAsync(agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
+            HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return HANK_OK;
+    }
+    note_primal_x(ctx, nullptr);
     const double *d_dagg = nullptr;
     if (use_x_fused(ctx, N)) {
         rc = x_dual(ctx, xhh, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
@@ -1221,6 +1299,8 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
     if (agg_out) HIPC(ctx, hipMemcpyAsync(agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipMemcpyAsync(dagg_out, d_dagg, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    note_primal_x(ctx, xhh);
+    ctx->stats[7]++;
     ctx->errmsg[0] = 0;
     return HANK_OK;
 }
@@ -1232,9 +1312,25 @@ int hank_fake_news(hank_ctx *ctx, double *F_out, double *Dv_out) {
     ENTER(ctx);
     if (!ctx || !F_out || !Dv_out) return fail(ctx, HANK_ERR_BAD_ARG, "null pointer");
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_fake_news");
+    if (!ctx->stationary)
+        return fail(ctx, HANK_ERR_NOT_READY, "hank_fake_news needs the recorded primal to be hank_primal at a CONSTANT path (the steady state; SteadyStateJacobian.jl:53-57): "
+                    "the last primal was recorded at a path that varies over time, or through a device-pointer entry");
     const Consts &c = ctx->c;
     const int P = c.P, G = c.G, N = c.n_hh, NP = P * N, S = 16;
     hipStream_t s = ctx->stream;
+    {   // ... and to be stationary: the policy of the first period equals the policy of the last (a constant path that is not the
+        // steady state of the boundary drifts; 1e-6 of the policy's scale is far above a converged value iteration's 1e-11)
+        std::vector<double> p0((size_t)G), p1((size_t)G);
+        HIPC(ctx, join_side(ctx));
+        HIPC(ctx, hipMemcpyAsync(p0.data(), ctx->R.pol, sizeof(double) * G, hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipMemcpyAsync(p1.data(), ctx->R.pol + (size_t)(P - 1) * G, sizeof(double) * G, hipMemcpyDeviceToHost, s));
+        HIPC(ctx, hipStreamSynchronize(s));
+        double scale = 0.0, diff = 0.0;
+        for (int k = 0; k < G; k++) { scale = std::max(scale, fabs(p1[k])); diff = std::max(diff, fabs(p0[k] - p1[k])); }
+        if (!(diff <= 1e-6 * std::max(scale, 1e-300)))
+            return fail(ctx, HANK_ERR_NOT_READY, "hank_fake_news: the recorded primal is not stationary (policy of period 1 and of period %d differ by %.3g): "
+                        "it needs hank_primal at the steady state with the steady state as both boundaries", P, diff);
+    }
     // 1. n_hh backward tangent sweeps (one batch) seeded at the last period: every lag of the policy response
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;

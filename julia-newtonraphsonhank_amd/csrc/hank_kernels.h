@@ -584,7 +584,7 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
     const int nbr_b = (g.nbx + RG - 1) / RG;
     const int bidx = (bidx_phys < nbr_b) ? xcd_contiguous(bidx_phys, nbr_b) : bidx_phys;
     const int nthr = 64 * c.n_e;
-    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, e = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the column in a scalar register: its bases become scalar)
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
     const int RB = 64 >> g.lgNC;
     const int n = bidy * g.NC + nl;
@@ -720,7 +720,7 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
     const int nbr_f = (g.nbx + RG - 1) / RG;            // regular blocks; the mass-point blocks behind them keep their place
     const int bidx = (g.N * (int)(sizeof(VT) / 8) <= HANK_XCDMAP_FWD_MAXN && bidx_phys < nbr_f) ? xcd_contiguous(bidx_phys, nbr_f) : bidx_phys;
     const int nthr = 64 * c.n_e;
-    const int lane = threadIdx.x & 63, e = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, e = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the column in a scalar register: its bases become scalar)
     const int nl = lane & (g.NC - 1), rl = lane >> g.lgNC;
     const int RB = 64 >> g.lgNC;
     const int n = bidy * g.NC + nl;

@@ -40,8 +40,17 @@ namespace hank {
 
 constexpr int XG = 8;             // groups = XCDs
 constexpr int XRW = 63;           // wealth rows per workgroup; lane 63 of every wave is the forward sweep's virtual row
-constexpr unsigned XSPIN_LIMIT = 1u << 21;
 enum { XERR_TIMEOUT = 1, XERR_PLACEMENT = 2 };
+// Every wait is bounded in TIME: s_memrealtime counts at 100 MHz for the whole chip, a wait that has lasted longer than
+// g_xwait_ticks (20 ms unless HANK_XWAIT_MS says otherwise at hank_create: four thousand periods' worth) marks the launch failed
+// and every later wait falls through, so the grid always drains and the host learns how long the sweep had waited.
+__device__ unsigned long long g_xwait_ticks = 2000000ull;
+struct XDeadline {
+    unsigned long long t0;
+    __device__ __forceinline__ XDeadline() : t0(__builtin_amdgcn_s_memrealtime()) {}
+    __device__ __forceinline__ bool expired(unsigned spins) const { return (spins & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > g_xwait_ticks; }
+    __device__ __forceinline__ unsigned waited_us() const { return (unsigned)((__builtin_amdgcn_s_memrealtime() - t0) / 100ull); }
+};
 
 struct XSync {                    // zeroed by a memset node before EVERY launch (66.9 KB, a multiple of 16)
     unsigned ticket[XG][32];      // [x][0]: workgroups that arrived on XCD x (one 128-B line each)
@@ -49,7 +58,7 @@ struct XSync {                    // zeroed by a memset node before EVERY launch
     unsigned flag[XG][64][32];    // [x][c][0]: the last barrier episode member c of group x has reached — one 128-B line per
                                   // member: 32 writers and 32 pollers on ONE line queue at one L2 channel (1.0-1.15 us per
                                   // episode against 0.71, scripts/ubench/xbar_bench.hip)
-    unsigned status[32];          // [0]: XERR_* (sticky), [1]: the XCD that raised it
+    unsigned status[32];          // [0]: XERR_* (sticky), [1]: the XCD that raised it, [2]: microseconds the wait that timed out had lasted
     unsigned pad[32];
 };
 
@@ -154,9 +163,11 @@ __device__ unsigned long long g_xwaves[2][32][XSTAMP_NP][16];
 #define XSTAMPW(sw, on, per, i, wave) do {} while (0)
 #endif
 
-__device__ inline void xfail(XSync *sy, unsigned code, int x) {
-    if (__hip_atomic_exchange(&sy->status[0], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+__device__ inline void xfail(XSync *sy, unsigned code, int x, unsigned waited_us = 0u) {
+    if (__hip_atomic_exchange(&sy->status[0], code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __hip_atomic_store(&sy->status[1], (unsigned)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sy->status[2], waited_us, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // dev knob HANK_XFAULT: the status word of a launch's sync block pre-set by the host
@@ -178,9 +189,10 @@ __device__ inline XGroup xgroup_join(XSync *sy, int *ctl) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the ticket is taken before it is counted
             __hip_atomic_fetch_add(&sy->total[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int ok = 1;
+            const XDeadline dl;
             for (unsigned spins = 0;; spins++) {
                 if (xldu(&sy->total[0]) >= gridDim.x) break;
-                if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) { xfail(sy, XERR_TIMEOUT, xcc); ok = 0; break; }
+                if (dl.expired(spins) || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) { xfail(sy, XERR_TIMEOUT, xcc, dl.waited_us()); ok = 0; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             ctl[0] = xcc; ctl[1] = (int)c; ctl[2] = (int)xldu(&sy->ticket[xcc][0]); ctl[3] = ok;
@@ -212,11 +224,12 @@ __device__ __forceinline__ void xbar_wait(XSync *sy, int x, int c, int members, 
     if (sync_wave) {
         const int lane = threadIdx.x & 63;
         if (lane == 0) *reinterpret_cast<volatile unsigned *>(&sy->flag[x][c][0]) = episode;
+        const XDeadline dl;
         for (unsigned spins = 0;; spins++) {
             const unsigned f = lane < members ? xldu(&sy->flag[x][lane][0]) : episode;
             if (__all((int)(f - episode) >= 0)) break;
-            if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
-                if (lane == 0) xfail(sy, XERR_TIMEOUT, x);
+            if (dl.expired(spins) || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
+                if (lane == 0) xfail(sy, XERR_TIMEOUT, x, dl.waited_us());
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -233,11 +246,12 @@ __device__ __forceinline__ void xbar_wait(XSync *sy, int x, int c, int members, 
 // Arrival skew up to the length of the first phase disappears from the critical path. xpoll: one wave, bounded.
 __device__ __forceinline__ void xpoll(XSync *sy, int x, int lo, int hi, unsigned need) {
     const int lane = threadIdx.x & 63;
+    const XDeadline dl;
     for (unsigned spins = 0;; spins++) {
         const unsigned f = (lane >= lo && lane <= hi) ? xldu(&sy->flag[x][lane][0]) : need;
         if (__all((int)(f - need) >= 0)) break;
-        if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
-            if (lane == 0) xfail(sy, XERR_TIMEOUT, x);
+        if (dl.expired(spins) || ((spins & 255u) == 255u && xldu(&sy->status[0]) != 0u)) {
+            if (lane == 0) xfail(sy, XERR_TIMEOUT, x, dl.waited_us());
             break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -392,7 +406,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
     const int Sact = (na + XRW - 1) / XRW;              // members that own rows
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }   // the whole group agrees on S
     if (cW >= Sact) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave index in a scalar register: column bases become scalar)
     const bool syncw = wv >= ne;                        // see k_xtan_back
     const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
     const int e = syncw ? 0 : wv;
@@ -491,7 +505,7 @@ __global__ void __launch_bounds__(MAXT) k_xvfi(XVfiArgs A) {
     const int Sact = (na + XRW - 1) / XRW;
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave index in a scalar register: column bases become scalar)
     const bool syncw = wv >= ne;
     const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
     const int e = syncw ? 0 : wv;
@@ -559,11 +573,12 @@ __global__ void __launch_bounds__(MAXT) k_xvfi(XVfiArgs A) {
             }
             xv4u f;
             f.x = episode; f.y = 1u; f.z = 0u; f.w = 0u;
+            const XDeadline dl;
             for (unsigned spins = 0;; spins++) {
                 if (lane < Sact) f = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 128, 0, 16);     // sc1: served by the XCD's L2
                 if (__all((int)(f.x - episode) >= 0)) break;
-                if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&A.sy->status[0]) != 0u)) {
-                    if (lane == 0) xfail(A.sy, XERR_TIMEOUT, x);
+                if (dl.expired(spins) || ((spins & 255u) == 255u && xldu(&A.sy->status[0]) != 0u)) {
+                    if (lane == 0) xfail(A.sy, XERR_TIMEOUT, x, dl.waited_us());
                     f.y = 2u;                               // leave the loop: the host reads the status word
                     break;
                 }
@@ -631,7 +646,7 @@ __global__ void __launch_bounds__(MAXT) k_xstat(XStatArgs A) {
     const int Sact = (na + XRW - 1) / XRW;
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave index in a scalar register: column bases become scalar)
     const bool syncw = wv >= ne;
     const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
     const int e = syncw ? 0 : wv;
@@ -731,11 +746,12 @@ __global__ void __launch_bounds__(MAXT) k_xstat(XStatArgs A) {
             }
             xv4u f;
             f.x = episode; f.y = 1u; f.z = 0u; f.w = 0u;
+            const XDeadline dl;
             for (unsigned spins = 0;; spins++) {
                 if (lane < Sact) f = __builtin_amdgcn_raw_buffer_load_b128(frs, lane * 128, 0, 16);
                 if (__all((int)(f.x - episode) >= 0)) break;
-                if (spins > XSPIN_LIMIT || ((spins & 255u) == 255u && xldu(&A.sy->status[0]) != 0u)) {
-                    if (lane == 0) xfail(A.sy, XERR_TIMEOUT, x);
+                if (dl.expired(spins) || ((spins & 255u) == 255u && xldu(&A.sy->status[0]) != 0u)) {
+                    if (lane == 0) xfail(A.sy, XERR_TIMEOUT, x, dl.waited_us());
                     f.y = 2u;
                     break;
                 }
@@ -771,6 +787,7 @@ struct XTanBackArgs {
     double *dpol;               // [P][groups][G][D]
     int groups;
     const int *src;             // [P][members] lo | hi << 8: the members whose rows period t's gathers of member c read (k_xsrc_back); null = all
+    int stall;                  // dev knob HANK_XFAULT=stall: member 0 of group 0 stops publishing after three periods — a wait that really times out
 };
 
 template <int D, int MAXT>
@@ -802,7 +819,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
         dxsh[(t_ * 3 + 1) * D + d_] = on ? A.dxw[ix] : 0.0;
         dxsh[(t_ * 3 + 2) * D + d_] = (on && c.n_hh > 2) ? A.dxt[ix] : 0.0;
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave index in a scalar register: column bases become scalar)
     const bool syncw = wv >= ne;                        // the extra wave (when the block has one) only runs the group barrier's poll
     const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
     const int e = syncw ? 0 : wv;
@@ -885,7 +902,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
             XSTAMP(0, son, i, 4);
             xbar_arrive(!syncw);                                         // this member's stores have reached L2
             XSTAMP(0, son, i, 5);
-            if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(i + 1));
+            if (sync_duty && !(A.stall && x == 0 && cW == 0 && i > 2)) xpublish(A.sy, x, cW, (unsigned)(i + 1));
             if (own) {      // the record the next trip needs (Y of period tx, X of period tx - 1): in flight while the others arrive
                 const size_t ro = (size_t)tx * G + pt;
                 ibY = R.ib[ro]; cA = R.A[ro]; cB = R.B[ro]; cu = R.u[ro]; cv = R.v[ro];
@@ -966,7 +983,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         if (A.all_members || (rec && ((w >> 17) & 1))) w = (w & ~0xffff) | ((Sact - 1) << 8);
         srcsh[k] = w;
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave index in a scalar register: column bases become scalar)
     const bool syncw = wv >= ne;                        // see k_xtan_back
     const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
     const int e = syncw ? 0 : wv;

@@ -266,7 +266,8 @@ class HouseholdBlock:
         """counters of the context (include/hank_hip.h: hank_stats)."""
         out = (C.c_int64 * 8)()
         self._chk(self._lib.hank_stats(self._ctx, out))
-        names = ("sweep_launches", "tangent_workspaces_allocated", "graphs_captured", "schedule", "fallbacks", "vfi_iterations")
+        names = ("sweep_launches", "tangent_workspaces_allocated", "graphs_captured", "schedule", "fallbacks", "vfi_iterations",
+                 "primal_memo_hits", "primal_sweeps")
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def policy_seq(self) -> np.ndarray:

@@ -174,3 +174,55 @@ def test_newton_with_the_reference_gmres_inner_solves(hank):
     # 5-7 steps with J̅ from the launched sweeps, 12 with the persistent ones forced everywhere, 19 with the Toeplitz J̅ — equal to
     # the unit-tangent one to 1e-9; the LU branch takes 4 with all of them)
     assert hank.NewtonRaphsonHANK.iterations <= it_lu + 20
+
+
+def test_reference_shaped_y_iteration_reuses_the_primal(hank, monkeypatch):
+    """NewtonRaphson.jl:91-95 calls JVP(fullFunction, x, y) for ~21 different y at ONE x and the reference's Dual pass recomputes
+    the primal every time. Through the reference's own signatures (the closure of :77-83, nothing about a primal in it) the
+    library runs ONE primal sweep and 20 tangent sweeps: the host-pointer hank_primal_jvp recognises the x on record. Results
+    equal the un-memoised ones (HANK_PRIMAL_MEMO=0) to the rounding of the aggregate sums in the default schedule, and bit for
+    bit where one implementation serves both (HANK_SCHEDULE=launch)."""
+    from hank_amd.BackwardIteration import household_block
+    m, ss, orc = ks_setup(50, 2, 100)
+    P = 99
+    x, Z = ks_paths(m, ss, "x1", 0.05)
+    exog = {"Z": Z}
+
+    def fullFunction(x_Vec):
+        policy_seqs = hank.BackwardIteration(x_Vec, exog, m, ss)
+        agg_seqs = hank.ForwardIteration(policy_seqs, m, ss)
+        padded = hank.assemble_full_xMat(x_Vec, agg_seqs, exog, m, ss, ss)
+        return hank.Residuals(padded, m)
+
+    xv = x.reshape(-1, order="F")
+    Ys = np.random.default_rng(7).standard_normal((20, 4 * P))
+    out = {}
+    for sched, memo in ((None, "1"), (None, "0"), ("launch", "1"), ("launch", "0")):
+        monkeypatch.setenv("HANK_PRIMAL_MEMO", memo)
+        if sched:
+            monkeypatch.setenv("HANK_SCHEDULE", sched)
+        else:
+            monkeypatch.delenv("HANK_SCHEDULE", raising=False)
+        if m._hip_block is not None:          # (the knobs are read at hank_create: a fresh context per round)
+            m._hip_block.close()
+            m._hip_block = None
+        hb = household_block(m)
+        st0 = hb.stats()
+        res = [hank.JVP(fullFunction, xv, y) for y in Ys]
+        st1 = hb.stats()
+        primal = st1["primal_sweeps"] - st0["primal_sweeps"]
+        hits = st1["primal_memo_hits"] - st0["primal_memo_hits"]
+        if memo == "1":
+            assert primal <= 1 and hits >= 19, (primal, hits)          # (<= 1: the x may already be on record from the previous round)
+        else:
+            assert primal == 20 and hits == 0, (primal, hits)
+        out[(sched, memo)] = np.array(res)
+    monkeypatch.delenv("HANK_PRIMAL_MEMO", raising=False)
+    monkeypatch.delenv("HANK_SCHEDULE", raising=False)
+    m._hip_block.close()
+    m._hip_block = None                       # (later tests get a context with the default knobs)
+    assert np.array_equal(out[("launch", "1")], out[("launch", "0")])
+    scale = np.abs(out[(None, "0")]).max()
+    assert np.max(np.abs(out[(None, "1")] - out[(None, "0")])) <= 1e-12 * scale
+    F_o, J_o = orc.ks_jvp(x, Ys.T.reshape(4, P, 20, order="F")[:, :, :3], Z, m.params.α, m.params.δ, ss.vars["KS"], ss.value, ss.D)
+    assert np.max(np.abs(out[(None, "1")][:3].T - J_o)) < 1e-10 * np.abs(J_o).max()

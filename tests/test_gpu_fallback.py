@@ -97,3 +97,36 @@ def test_async_entries_report_the_sweep_error_at_check(hank, monkeypatch):
         hb.check()
     assert ei.value.code == hank.hip.HANK_ERR_SWEEP
     hb.close()
+
+
+def test_a_wait_that_really_times_out_is_bounded_in_time(hank, monkeypatch):
+    """HANK_XFAULT=stall: member 0 of group 0 of the persistent backward tangent sweep stops publishing after three periods, so its
+    neighbours' waits run into the deadline (HANK_XWAIT_MS, s_memrealtime — a time, not a spin count), every later wait falls
+    through and the grid drains. The host-pointer entry then returns the launches' numbers, well within 0.2 s; a forced schedule
+    reports how long the sweep had waited."""
+    import time
+    m, ss, _ = ks_setup(130, 3, 20)
+    P = 19
+    x, _ = ks_paths(m, ss, "x1", 0.05)
+    y = np.random.default_rng(1).standard_normal((2, P, 5))
+    ref = _block(hank, m, monkeypatch, sched="launch")
+    ref.set_boundary(ss.value, ss.D)
+    ref.primal(x[2:4]); d0 = ref.jvp(y)
+    monkeypatch.setenv("HANK_XWAIT_MS", "5")
+    hb = _block(hank, m, monkeypatch, fault="stall")
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(x[2:4])
+    t0 = time.perf_counter()
+    d = hb.jvp(y)
+    el = time.perf_counter() - t0
+    assert np.array_equal(d, d0) and hb.stats()["fallbacks"] == 1
+    assert el < 0.2, el
+    hb.close()
+    hb = _block(hank, m, monkeypatch, fault="stall", sched="xcd")
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(x[2:4])
+    with pytest.raises(hank.HankHIPError, match=r"a wait timed out after \d+\.\d ms"):
+        hb.jvp(y)
+    hb.close()
+    monkeypatch.delenv("HANK_XWAIT_MS", raising=False)
+    ref.close()

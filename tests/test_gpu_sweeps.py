@@ -138,8 +138,10 @@ def _forced(hank, m, sched):
 
 def test_dual_sweep_equals_primal_then_jvp(hank):
     """hank_primal_jvp (value and partials in one pass) == hank_primal followed by hank_jvp, and it leaves the same record
-    behind: bit for bit within one implementation (per-period launches; XCD-local persistent sweeps), and to rounding of
-    the aggregate sums in the default schedule, which mixes the two (policies and their partials stay bit-identical)."""
+    behind: bit for bit with the per-period launches; to rounding of the aggregate sums with the XCD-local persistent sweeps
+    (their dual pass carries D_t along with its partials and takes the term dpol_t . D_t at the target rows, the tangent sweep
+    at a recorded primal takes it at the source rows: another order of the same sum) and in the default schedule, which mixes
+    the two implementations. Policies and their partials stay bit-identical throughout."""
     for (na, ne, T, N) in [(50, 2, 100, 3), (37, 3, 9, 5), (500, 4, 300, 1)]:
         m, ss, orc = ks_setup(na, ne, T)
         P = T - 1
@@ -147,7 +149,7 @@ def test_dual_sweep_equals_primal_then_jvp(hank):
         y = np.random.default_rng(5).standard_normal((2, P, N))
         for sched in ("launch", "xcd", None):
             hb = _forced(hank, m, sched) if sched else hank.household_block(m)
-            same = np.array_equal if sched else (lambda a, b: np.max(np.abs(a - b)) <= 1e-13 * max(np.max(np.abs(b)), 1e-300))
+            same = np.array_equal if sched == "launch" else (lambda a, b: np.max(np.abs(a - b)) <= 1e-13 * max(np.max(np.abs(b)), 1e-300))
             hb.set_boundary(ss.value, ss.D)
             agg0 = hb.primal(x[2:4]); dagg0 = hb.jvp(y); pol0 = hb.policy_seq(); dpol0 = hb.dpolicy_seq(N)
             hb.primal(x[2:4] * 1.01)                       # scramble the record

@@ -46,7 +46,7 @@ def test_forced_persistent_sweeps_match_the_oracle(hank, n_a, n_e, T, N, shock):
     hb.set_boundary(ss.value, ss.D)
     agg, dagg = hb.primal_jvp(x[2:4], y)
     st = hb.stats()
-    assert st["schedule"] == 1 and st["fallbacks"] == 0 and st["sweep_launches"] >= 4
+    assert st["schedule"] == 1 and st["fallbacks"] == 0 and st["sweep_launches"] >= 3
     cols, pols = [], []
     for c0 in range(0, N, SUPPORTED_N[-1]):
         c1 = min(N, c0 + SUPPORTED_N[-1])
@@ -63,10 +63,13 @@ def test_forced_persistent_sweeps_match_the_oracle(hank, n_a, n_e, T, N, shock):
     close(hb.dpolicy_seq(N).transpose(2, 0, 1, 3), np.concatenate(pols, axis=-1))
     D = hb.dist_seq()
     np.testing.assert_allclose(D.sum(axis=(0, 1)), 1.0, atol=1e-12)
-    # one primal, then JVPs at its record — and again: bit-reproducible (fixed summation order, no atomics)
+    # one primal, then JVPs at its record — and again: bit-reproducible (fixed summation order; the LDS adds of one wave execute
+    # in program order). The dual pass takes the term dpol_t . D_t of the aggregate at the target rows, the sweep at a recorded
+    # primal at the source rows: the same sum in another order
     assert np.array_equal(hb.primal(x[2:4]), agg)
     again = hb.jvp(y)
-    assert np.array_equal(again, dagg) and np.array_equal(hb.jvp(y), again)
+    close(again, dagg, rel=1e-13)
+    assert np.array_equal(hb.jvp(y), again)
     hb.close()
 
 
