@@ -68,7 +68,7 @@ def check_timed_output(m, ss, x, dx_host, agg_gpu, dagg_gpu):
             "tolerance": 1e-10}
 
 
-def cpu_baseline(m, ss, x, Z, budget_s=12.0):
+def cpu_baseline(m, ss, x, Z, budget_s=6.0):
     """the reference-style CPU path (oracle: dual numbers, primal recomputed on every JVP,
     NewtonRaphson.jl:95) timed on a bounded sample of the same workload: on ONE host core (the
     reference is single-threaded) and, beside it, on all the host cores this process may use, one
@@ -105,6 +105,25 @@ def cpu_baseline(m, ss, x, Z, budget_s=12.0):
             "sample": f"{n1} single-tangent JVPs (dual-number pipeline incl. primal, {shape}) in {el1:.1f} s on 1 core",
             "all_cores": {"value": nall / elall, "unit": "JVPs/s", "cores": cores, "kind": "port",
                           "sample": f"{nall} single-tangent JVPs, one per thread at a time, in {elall:.1f} s on {cores} threads"}}
+
+
+def model_ceiling(G, N, n_e):
+    """What this arithmetic can reach on this chip per period and sweep ("the path is fp64-issue-bound before
+    it is HBM-bound"): the larger of the HBM time of the algorithmic bytes and the issue time of the fp64 work — about 80 lane-
+    instructions per point and direction at n_e = 11 (10 Y half, 6 + 2 n_e X half / mixing, the rest index, LDS and select
+    instructions; counters: profiles/r03n256_*), 1 024 SIMDs issuing one wave-instruction (64 lanes) per 4 clocks at 2.4 GHz —
+    plus, at narrow batches, the floor of a dependent period (2.5 us: one barrier + one L2 round trip + the drain of the state
+    stores, the persistent sweeps' stamps; a launch per period has 6.5-7 us)."""
+    bytes_per_period = G * 8 * (1 + N)
+    t_hbm = bytes_per_period / (HBM_PEAK_GBS * 1e9)
+    lane_instr = (58 + 2 * n_e) * G * N
+    t_issue = lane_instr / (1024 * 64 * 2.4e9 / 4)
+    t_floor = 2.5e-6
+    t = max(t_hbm, t_issue, t_floor)
+    return {"GBs": bytes_per_period / t / 1e9, "frac_of_hbm_peak": bytes_per_period / t / 1e9 / HBM_PEAK_GBS,
+            "bound": "hbm" if t == t_hbm else ("fp64 issue" if t == t_issue else "dependent-period latency"),
+            "inputs": {"hbm_us": 1e6 * t_hbm, "fp64_issue_us": 1e6 * t_issue, "period_floor_us": 1e6 * t_floor,
+                       "lane_instructions_per_point_direction": 58 + 2 * n_e}}
 
 
 def kernel_source_sha16():
@@ -178,7 +197,7 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
                            # the same object as the headline's, for the slower sweep of the wide batch (HIP events on the library's stream)
                            "roofline": {"bound": "hbm", "kernel": ("k_xtan_" if hb.stats()["schedule"] == 1 else "k_fused_") + ("back" if slow == kb else "fwd"),
                                         "achieved": ach_w, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_w / HBM_PEAK_GBS, "traffic": None,
-                                        "sweep_ms": tm[slow]["ms"], "launches": tm[slow]["launches"]},
+                                        "sweep_ms": tm[slow]["ms"], "launches": tm[slow]["launches"], "model_ceiling": model_ceiling(hb.G, Nw, hb.n_e)},
                            "whole_batch": {"B_alg_bytes": b_alg_w, "achieved_GBs": b_alg_w / el / 1e9, "frac_of_hbm_peak": b_alg_w / el / 1e9 / HBM_PEAK_GBS}}
     # the y-iteration's access pattern (NewtonRaphson.jl:91-111): ONE primal, then JVP batches at that record
     hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
@@ -200,6 +219,48 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
         hb.jvp_dev(d_dx1.data_ptr(), 1, d_outj.data_ptr())
     hb.sync()
     extra["single_tangent_jvp_ms"] = 1e3 * (time.perf_counter() - t0) / reps
+    # BASELINE configs[1]: 500x4, T=300, ONE tangent at a recorded primal (its 9.6 MB policy sequence lives in the Infinity Cache:
+    # the figure is an effective bandwidth from the algorithmic bytes)
+    try:
+        from conftest import ks_paths as _kp, ks_setup as _ks
+        m1, ss1, _ = _ks(500, 4, 300)
+        wd1, pd1 = m1.heterogeneity["wealth"], m1.heterogeneity["productivity"]
+        hb1 = type(hb)(wd1.grid, pd1.grid, pd1.transition, m1.params.β, m1.params.γ, m1.params.borrow_cons, 300)
+        hb1.set_boundary(ss1.value, ss1.D)
+        x1, _ = _kp(m1, ss1, "x1", 0.01)
+        P1 = 299
+        hb1.primal(x1[2:4])
+        d1 = torch.randn(2 * P1, dtype=torch.float64, device=dev)
+        o1 = torch.empty(P1, dtype=torch.float64, device=dev)
+        hb1.jvp_dev(d1.data_ptr(), 1, o1.data_ptr()); hb1.sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            hb1.jvp_dev(d1.data_ptr(), 1, o1.data_ptr())
+        hb1.sync()
+        ms1 = 1e3 * (time.perf_counter() - t0) / 20
+        tm1 = hb1.last_timings()
+        slow1 = max(("tangent_backward", "tangent_forward"), key=lambda k: tm1[k]["ms"])
+        bytes1 = P1 * 2000 * 8            # one sweep moves the policy partials of one direction: P G 8 bytes
+        extra["config1_single_tangent"] = {
+            "workload": "ks_500x4_T300_N1", "single_tangent_jvp_ms": ms1, "JVPs_per_s": 1e3 / ms1,
+            "roofline": {"bound": "hbm", "kernel": "k_xtan_back" if slow1 == "tangent_backward" else "k_xfwd", "achieved": bytes1 / (1e-3 * tm1[slow1]["ms"]) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes1 / (1e-3 * tm1[slow1]["ms"]) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "sweep_ms": tm1[slow1]["ms"], "launches": tm1[slow1]["launches"],
+                         "note": "ONE persistent launch per sweep; the 9.6 MB policy-partials sequence stays in the 256 MB Infinity Cache",
+                         "model_ceiling": model_ceiling(2000, 1, 4)}}
+        hb1.close()
+    except Exception as e:              # noqa: BLE001
+        extra["config1_single_tangent"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # BASELINE configs[4]: one-asset HANK 1000x7, T=500, Newton to convergence, both inner loops (examples/solve_hank.py)
+    extra["config4_one_asset_hank"] = []
+    for inner in ("fixed_point", "krylov"):
+        try:
+            from examples.solve_hank import solve as solve_hank
+            res = solve_hank(1000, 7, 500, inner=inner)[0]
+            res.pop("impact", None)
+        except Exception as e:          # noqa: BLE001
+            res = {"model": "one-asset HANK", "grid": "1000x7", "T": 500, "inner": inner, "error": f"{type(e).__name__}: {e}"[:300]}
+        extra["config4_one_asset_hank"].append(res)
     # configs[1]'s grid with a mild shock and with RunMain.jl's Z_t = 1 + 0.8^t, then the headline grid
     # (the last two: the headline grid with the reference's damped fixed point, then with the opt-in Krylov inner loop)
     for n_a, n_e, shock, inner in ((500, 4, 0.01, "fixed_point"), (500, 4, 0.8, "fixed_point"), (2000, 11, 0.01, "fixed_point"), (2000, 11, 0.01, "krylov")):
@@ -354,7 +415,8 @@ def devicegroup_main(args):
     m, ss = load_or_solve_ss(n_a, n_e, T)
     x, _ = ks_paths(m, ss, "x1", 0.01)
     xf = np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()
-    first = h.household_block(m, device=0)
+    wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    first = h.HouseholdBlock(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T, device=0)
     first.set_boundary(ss.value, ss.D)
     blocks = [first] + [first.clone(device=d) for d in range(1, args.gpus)]
     bufs = []
@@ -554,6 +616,7 @@ def main(argv=None):
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale, "traffic_detail": pmc,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_launch_s,
+                         "model_ceiling": model_ceiling(G, N, n_e),
                          "schedule": "xcd-persistent" if schedule == 1 else "launch-per-period",
                          "note": "avg launch = HIP-event time of the sweep's kernels on the library's stream / launches"},
             "whole_batch": {"B_alg_bytes": b_alg_batch, "achieved_GBs": b_alg_batch / (1e-3 * ms_per_step) / 1e9,

@@ -36,6 +36,8 @@ class LinearizedFunction:
     """F(x) evaluated once + cheap J(x)·y products at that fixed x (the y-iteration's access pattern,
     NewtonRaphson.jl:91-105). Tangent batches (n, N) go through ONE hank_jvp."""
 
+    exact_residual_layer = False        # True: J(x)·y through the compiled equations under a Dual at every call (tests compare the two)
+
     def __init__(self, x, exog_paths, mod: SequenceModel, ss_initial, ss_ending):
         self.x = np.asarray(x, dtype=np.float64)
         self.mod, self.exog_paths, self.ss_initial, self.ss_ending = mod, exog_paths, ss_initial, ss_ending
@@ -45,8 +47,55 @@ class LinearizedFunction:
         self._record_primal()
         het = vars_of_type(mod, "heterogeneous")
         self.het = het
-        self.Fx = Residuals(assemble_full_xMat(self.x, {k: self.agg for k in het}, exog_paths, mod,
-                                               ss_initial, ss_ending), mod)
+        self._xMat = assemble_full_xMat(self.x, {k: self.agg for k in het}, exog_paths, mod, ss_initial, ss_ending)
+        self.Fx = Residuals(self._xMat, mod)
+        self._Rx = self._Ragg = None        # the residual layer's linearisation at this x, built at the first jvp
+
+    def _linearise_residuals(self):
+        """∂R/∂x and ∂R/∂agg at this x as sparse maps, from ONE evaluation of the compiled equations under a Dual: x — and with
+        it the residual layer's linearisation — is fixed for the whole y-iteration (NewtonRaphson.jl:91-111), so the ≈ 21 inner
+        iterations need not re-seed a Dual and re-evaluate the equations under it each time (Aggregation.jl:20-22,
+        GeneralStructures.jl:329-377: the padded matrix is a selection of x, the aggregates and constants). Direction
+        (row r, colour k) perturbs variable r in every padded column c with c mod W == k; the W = 1 + max_lag + max_lead columns
+        a period's equations read have distinct colours, so each direction is one entry of that period's Jacobian block."""
+        import scipy.sparse as sp
+        from .GeneralStructures import var_names
+        mod, cs = self.mod, self.mod.compspec
+        P, n_v, n_endog, max_lag, max_lead = cs.T - 1, cs.n_v, cs.n_endog, cs.max_lag, cs.max_lead
+        W = 1 + max_lag + max_lead
+        T_pad = P + max_lag + max_lead
+        n_eq = len(mod.equations)
+        xp = np.zeros((n_v, T_pad, n_v * W))
+        cols = np.arange(T_pad)
+        for r in range(n_v):
+            xp[r, cols, r * W + cols % W] = 1.0
+        res = Residuals(Dual(self._xMat, xp), mod)
+        Pm = np.asarray(res.p).reshape(P, n_eq, n_v, W)                   # [t, q, r, colour]: rows are ordered q + n_eq t, directions r W + colour
+        keys = var_names(mod)
+        endog = {keys.index(k): j for j, k in enumerate(vars_of_type(mod, "endogenous"))}
+        hetr = {keys.index(k): j for j, k in enumerate(self.het)}
+        rx, cx, vx, ra, ca, va = [], [], [], [], [], []
+        t = np.arange(P)
+        for k in range(W):
+            c = t + (k - t) % W                   # the padded column of colour k inside period t's window [t, t + W)
+            s_ = c - max_lag                      # ... as a transition period (boundary columns are constants)
+            ok = (s_ >= 0) & (s_ < P)
+            for r in range(n_v):
+                if r not in endog and r not in hetr:
+                    continue                      # exogenous paths carry no tangent
+                for q in range(n_eq):
+                    v = Pm[:, q, r, k]
+                    nz = ok & (v != 0.0)
+                    if not nz.any():
+                        continue
+                    rows = q + n_eq * t[nz]
+                    if r in endog:
+                        rx.append(rows); cx.append(endog[r] + n_endog * s_[nz]); vx.append(v[nz])
+                    else:
+                        ra.append(rows); ca.append(hetr[r] * P + s_[nz]); va.append(v[nz])
+        cat = lambda L, dt: np.concatenate(L) if L else np.zeros(0, dtype=dt)
+        self._Rx = sp.csr_matrix((cat(vx, float), (cat(rx, int), cat(cx, int))), shape=(n_eq * P, n_endog * P))
+        self._Ragg = sp.csr_matrix((cat(va, float), (cat(ra, int), cat(ca, int))), shape=(n_eq * P, len(self.het) * P))
 
     def _record_primal(self):
         """(re-)run the Float64 sweep at x on the model's device context and take ownership of its record: the
@@ -85,9 +134,15 @@ class LinearizedFunction:
                 padded[:, :, :len(nz)] = sub
                 sub = padded
             dagg[:, nz] = self.hb.jvp(sub)[:, :len(nz)]
-        agg = {k: Dual(self.agg, dagg) for k in self.het}
-        res = Residuals(assemble_full_xMat(xd, agg, self.exog_paths, self.mod, self.ss_initial, self.ss_ending), self.mod)
-        return res.p[:, 0].copy() if single else res.p.copy()
+        if self.exact_residual_layer:           # the reference's way: re-evaluate the equations under the Dual every time
+            agg = {k: Dual(self.agg, dagg) for k in self.het}
+            res = Residuals(assemble_full_xMat(xd, agg, self.exog_paths, self.mod, self.ss_initial, self.ss_ending), self.mod)
+            return res.p[:, 0].copy() if single else res.p.copy()
+        if self._Rx is None:
+            self._linearise_residuals()
+        Y = y[:, None] if single else y
+        out = self._Rx @ Y + self._Ragg @ np.tile(dagg, (len(self.het), 1))     # (one heterogeneous variable per household block: every het row sees the block's aggregate)
+        return out[:, 0].copy() if single else out
 
 
 def _gmres(J, b, x0):
@@ -117,10 +172,36 @@ def _lu_solver(J):
     return lambda b: sla.lu_solve(lu, b)
 
 
+_INV_CACHE = []         # [(J, apply)]
+
+
+def _device_inverse_solver(J):
+    """J̅⁻¹·b as ONE dense matrix-vector product on the GPU (a library GEMV: torch → rocBLAS) with the explicit inverse, formed once
+    per J̅ (torch.linalg.inv on the device): at the one-asset HANK size (n = 3 493) the host's two triangular solves read 97 MB per
+    inner iteration and took as long as the device's tangent sweeps (2.1 ms against 2.9 ms, scripts/dev_profile_newton.py). J̅⁻¹
+    is a preconditioner here — the fixed point of the y-iteration is J(x)⁻¹F(x) whatever its accuracy. Returns None without a GPU."""
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return None
+    except Exception:       # noqa: BLE001
+        return None
+    if not (_INV_CACHE and _INV_CACHE[0][0] is J):
+        A = J.toarray() if hasattr(J, "toarray") else np.asarray(J)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        Ainv = torch.linalg.inv(torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(dev))
+
+        def apply(b, Ainv=Ainv, dev=dev):
+            return (Ainv @ torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).to(dev)).cpu().numpy()
+
+        _INV_CACHE[:] = [(J, apply)]
+    return _INV_CACHE[0][1]
+
+
 @host_algebra
 def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, precond=None,
                 α: float | None = None, γ: float = 1.5, ε: float = 1e-9, verbose: bool = False, max_inner: int = 10_000,
-                linear_solver: str = "lu", inner: str = "fixed_point"):
+                linear_solver: str = "auto", inner: str = "fixed_point"):
     """inner iteration for the search direction y with J(x)·y = F(x) (NewtonRaphson.jl:65-114).
 
     inner="fixed_point" (default, the reference): y ← y + α·J̅⁻¹(F(x) − J(x)·y). The reference accepts α (:72) and
@@ -133,7 +214,11 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
     y_old, M, R = np.ones(n), np.ones(n), np.ones(n)
     Fx = lin.Fx
     i = 1
-    solve = _lu_solver(J̅) if linear_solver == "lu" else None
+    solve = None
+    if linear_solver in ("auto", "device") and len(y) >= 2000:      # (below that the host's LU solve takes a tenth of a millisecond)
+        solve = _device_inverse_solver(J̅)
+    if solve is None and linear_solver in ("auto", "lu", "device"):
+        solve = _lu_solver(J̅)
     if inner == "krylov":
         count = [0]
 
@@ -148,6 +233,10 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
         AP = spla.LinearOperator((n, n), matvec=lambda z: matvec(Pinv.matvec(z)), dtype=np.float64)
         z, info = spla.gmres(AP, Fx, rtol=min(1e-10, ε), atol=1e-3 * ε, restart=min(30, n), maxiter=max(1, max_inner // 30))
         y = Pinv.matvec(z)
+        if info != 0:       # not converged within maxiter (or a breakdown): the step is still a descent direction of the preconditioned
+            import warnings  # system, but the caller must know it is not the Newton step
+            warnings.warn(f"y_Iteration(inner='krylov'): GMRES returned info={info} after {count[0]} JVPs; "
+                          f"‖F − J y‖ = {np.linalg.norm(Fx - lin.jvp(y)):.3e}", RuntimeWarning, stacklevel=2)
         y_Iteration.last_jvp_count = count[0]
         y_Iteration.total_jvps = getattr(y_Iteration, "total_jvps", 0) + count[0]
         if verbose:
@@ -178,7 +267,7 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
 
 @host_algebra
 def NewtonRaphsonHANK(x_0, J̅, exog_paths, mod: SequenceModel, ss_initial, ss_ending, *, ε: float = 1e-9,
-                      verbose: bool = False, linear_solver: str = "lu", inner: str = "fixed_point", α: float | None = None):
+                      verbose: bool = False, linear_solver: str = "auto", inner: str = "fixed_point", α: float | None = None):
     """outer Newton loop (NewtonRaphson.jl:27-46): x ← x − y until ‖y‖ ≤ ε or 100 iterations. `inner` / `α`: see y_Iteration
     (defaults = the reference's damped fixed point)."""
     x = np.asarray(x_0, dtype=np.float64)

@@ -48,10 +48,16 @@ class SSAssembler:
             # loop, which handles it through the kron of the transitions. Errors of the device sweeps themselves
             # (KnotsNotSorted / DomainError at a price iterate) surface from F(p) as they do on the host.
             from .BackwardIteration import household_block
-            from .hip import HankHIPError
+            from .hip import HANK_ERR_BAD_ARG, HANK_ERR_NO_DEVICE, HankHIPError
             try:
                 household_block(model)
-            except (ValueError, HankHIPError):
+            except ValueError:
+                self.vfi_on_device = False
+            except HankHIPError as e:
+                # only "this model / this machine cannot": a device fault (out of memory, a refused launch, a failed sweep)
+                # must not turn into a silent hundredfold slowdown on the host loop
+                if e.code not in (HANK_ERR_BAD_ARG, HANK_ERR_NO_DEVICE):
+                    raise
                 self.vfi_on_device = False
         self.vfi_steps = 0
         self.all_keys = var_names(model)

@@ -19,7 +19,7 @@ _CONTROLLER = None
 def host_threads():
     """context manager CAPPING the BLAS / OpenMP thread pools at HANK_HOST_THREADS for the enclosed host algebra: a pool that
     is already smaller (OMP_NUM_THREADS=1 under torchrun, say) is left as it is — `threadpool_limits(limits=n)` alone would
-    raise it to n. The library scan is done once per process (ThreadpoolController)."""
+    raise it to n."""
     global _CONTROLLER
     try:
         from threadpoolctl import ThreadpoolController
@@ -31,8 +31,11 @@ def host_threads():
         n = 8
     if n <= 0:
         return contextlib.nullcontext()
-    if _CONTROLLER is None:
-        _CONTROLLER = ThreadpoolController()
+    # the scan is cheap next to the algebra it guards and a BLAS / OpenMP runtime loaded later (a late torch import, say) must
+    # be capped too: re-scan when the set of loaded libraries has changed
+    fresh = ThreadpoolController()
+    if _CONTROLLER is None or len(fresh.lib_controllers) != len(_CONTROLLER.lib_controllers):
+        _CONTROLLER = fresh
     over = [lib for lib in _CONTROLLER.lib_controllers if (lib.num_threads or 0) > n]
     if not over:
         return contextlib.nullcontext()

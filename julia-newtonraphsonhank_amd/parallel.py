@@ -90,6 +90,8 @@ class DeviceGroup:
         self.devices = list(devices)
         if not self.devices:
             raise ValueError("DeviceGroup needs at least one device")
+        if block.device is not None and block.device != self.devices[0]:
+            raise ValueError(f"DeviceGroup: `block` lives on device {block.device}, devices[0] is {self.devices[0]}")
         self.blocks = [block] + [block.clone(device=d) for d in self.devices[1:]]
         from concurrent.futures import ThreadPoolExecutor
         self._pool = ThreadPoolExecutor(max_workers=len(self.blocks))

@@ -34,7 +34,11 @@ end
 const _FAMILIES = Dict(:ValueFunction => (0, (:r, :w)),                # KrusellSmith.jl:43-83, :53-54
                        :HANKValueFunction => (1, (:r, :om, :Tr)))      # one-asset HANK (not in the reference)
 
-const _CTX = Dict{Tuple{UInt,Int},HankCtx}()     # one device context per (SequenceModel, HIP device); device -1 = the current one
+# one device context per (SequenceModel, HIP device); device -1 = the current one. Keyed on the model ITSELF (an IdDict keeps it
+# alive: an objectid can be recycled by a later model and hand it a context built for other grids) and guarded by a lock:
+# sharded_jvp_columns reaches it from several tasks.
+const _CTX = IdDict{Any,Dict{Int,HankCtx}}()
+const _CTX_LOCK = ReentrantLock()
 
 function _check(ctx::Ptr{Cvoid}, rc::Cint)
     rc == 0 && return
@@ -45,7 +49,8 @@ end
 # `device`: HIP device ordinal (hank_create_on) — one context per GPU of a node lets ONE Julia process shard the columns of
 # a tangent batch over the GPUs (sharded_jvp_columns below); `nothing` = the calling thread's current device (hank_create)
 function hank_context(model::SequenceModel; device::Union{Nothing,Integer} = nothing)
-    get!(_CTX, (objectid(model), device === nothing ? -1 : Int(device))) do
+    lock(_CTX_LOCK) do
+    get!(get!(() -> Dict{Int,HankCtx}(), _CTX, model), device === nothing ? -1 : Int(device)) do
         w = model.heterogeneity.wealth; p = model.heterogeneity.productivity
         a = collect(Float64, w.grid); z = collect(Float64, p.grid); Π = Matrix{Float64}(p.transition)
         haskey(_FAMILIES, nameof(model.value_fn)) || error("no native kernel family for $(model.value_fn)")
@@ -63,6 +68,7 @@ function hank_context(model::SequenceModel; device::Union{Nothing,Integer} = not
         @assert ccall((:hank_n_hh, LIBHANK), Cint, (Ptr{Cvoid},), ref[]) == length(rows)
         finalizer(c -> ccall((:hank_destroy, LIBHANK), Cint, (Ptr{Cvoid},), c.ptr), ctx)
         ctx
+    end
     end
 end
 
@@ -156,12 +162,15 @@ function sharded_jvp_columns(model::SequenceModel, ss_end, ss_initial, xhh::Matr
     dagg = Matrix{Float64}(undef, P, N)
     base, extra = divrem(N, W)
     value = Matrix{Float64}(ss_end.value); D0 = Vector{Float64}(ss_initial.D)
+    ctxs = [hank_context(model; device = dev) for dev in devices]      # resolved (or created) on the calling task, before any task is spawned
+    # (the blocking ccalls only overlap when Julia runs at least length(devices) threads: `julia -t N`; with one thread the tasks
+    # serialise — then drive the contexts through the asynchronous hank_*_dev entries instead)
     @sync for (g, dev) in enumerate(devices)
         lo = (g - 1) * base + min(g - 1, extra) + 1
         hi = lo + base + (g <= extra ? 1 : 0) - 1
         hi < lo && continue
         Threads.@spawn begin                     # a context is used by ONE task at a time; different contexts run concurrently
-            ctx = hank_context(model; device = dev)
+            ctx = ctxs[g]
             _check(ctx.ptr, ccall((:hank_set_boundary, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), ctx.ptr, value, D0))
             agg = Vector{Float64}(undef, P)
             blk = dxhh[:, :, lo:hi]

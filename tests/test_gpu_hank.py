@@ -101,3 +101,30 @@ def test_monetary_shock_converges(hank):
     # a contractionary shock: the real rate rises, output and inflation fall on impact
     assert out["impact"]["r"] > 0 or out["impact"]["i"] > 0
     assert out["impact"]["Y"] < 0 and out["impact"]["infl"] < 0
+
+
+def test_residual_layer_linearised_once_equals_the_dual_evaluation(hank):
+    """LinearizedFunction.jvp through the sparse maps dR/dx, dR/dagg built once per x (one Dual evaluation of the compiled
+    equations, colours = padded column mod (1 + max_lag + max_lead)) against the reference's way — the equations re-evaluated
+    under the Dual at every call (Aggregation.jl:20-22) — for a model with leads AND lags around the block (one-asset HANK) and
+    for Krusell-Smith, single tangents and a batch, away from the steady state."""
+    from conftest import ks_paths, ks_setup
+    from examples.solve_hank import build
+    m, ss = build(80, 3, 40)
+    P = 39
+    keys = hank.vars_of_type(m, "endogenous")
+    rng = np.random.default_rng(11)
+    x = np.tile(np.array([ss.vars[k] for k in keys]), P) * (1.0 + 1e-3 * rng.standard_normal(len(keys) * P))
+    ei = 0.0025 * 0.6 ** np.arange(P)
+    cases = [(m, ss, x, {"ei": ei})]
+    mk, ssk, _ = ks_setup(50, 2, 100)
+    xk, Zk = ks_paths(mk, ssk, "x1", 0.05)
+    cases.append((mk, ssk, xk.reshape(-1, order="F"), {"Z": Zk}))
+    for mod, s_, x_, exog in cases:
+        lin = hank.LinearizedFunction(x_, exog, mod, s_, s_)
+        Y = rng.standard_normal((len(x_), 5))
+        fast1, fastN = lin.jvp(Y[:, 0]), lin.jvp(Y)
+        lin.exact_residual_layer = True
+        ref1, refN = lin.jvp(Y[:, 0]), lin.jvp(Y)
+        scale = np.abs(refN).max()
+        assert np.max(np.abs(fast1 - ref1)) <= 1e-12 * scale and np.max(np.abs(fastN - refN)) <= 1e-12 * scale

@@ -1,8 +1,10 @@
 """The steady-state Jacobian from its Toeplitz structure (hank_fake_news + the reference's recursion,
 SteadyStateJacobian.jl:187-256, :293-323, :358-387) against the same matrix assembled column by column from unit-tangent
-JVPs of the full pipeline (method="columns", itself checked against the oracle in test_gpu_api.py). Tolerance: 1e-8 of the
-largest entry (observed 5e-10 .. 1.3e-9) — the two differ only by how stationary the recorded steady state is (VFI tolerance
-1e-11) and by summation order."""
+JVPs of the full pipeline (method="columns"), and — directly — against the CPU oracle: the household block's Jacobian columns
+against the oracle's unit-tangent household block, the assembled J̅ against the oracle's full-pipeline JVP on the reference's
+seven columns (test_SteadyState.jl:194-231). Tolerance: 1e-8 of the largest entry (observed 5e-10 .. 1.3e-9) — the Toeplitz
+form assumes the recorded steady state is exactly stationary (VFI tolerance 1e-11), the oracle differentiates the path as it
+is."""
 import sys
 from pathlib import Path
 
@@ -94,3 +96,64 @@ def test_krylov_inner_loop_reaches_the_same_path_with_fewer_jvps(hank):
     assert np.max(np.abs(out["undamped"][0] - out["reference"][0])) < 1e-8
     assert out["krylov"][1] < out["reference"][1] / 2
     assert out["undamped"][1] < out["reference"][1]
+
+
+@pytest.mark.parametrize("n_a,n_e,T", [(50, 2, 100), (130, 3, 20)])
+def test_toeplitz_household_jacobian_against_the_oracle(hank, n_a, n_e, T):
+    """household_jacobian(*hb.fake_news()) columns [0, 1, P//2, P-2, P-1] for every household input against the ORACLE's household
+    block under unit tangents (SteadyStateJacobian.jl:300-305, :363-371): 1e-8 of the largest entry."""
+    from oracle.oracle import pad_N
+    from hank_amd.SteadyStateJacobian import household_jacobian
+    from hank_amd.BackwardIteration import household_block
+    m, ss, orc = ks_setup(n_a, n_e, T)
+    P = T - 1
+    hb = household_block(m)
+    x = np.tile(np.array([[ss.vars["r"]], [ss.vars["w"]]]), (1, P))
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(x)
+    Jhh = household_jacobian(*hb.fake_news())
+    cols = sorted(set([0, 1, P // 2, P - 2, P - 1]))
+    N = 2 * len(cols)
+    Nc = pad_N(N)
+    xr = np.zeros((P, 1 + Nc)); xw = np.zeros((P, 1 + Nc))
+    xr[:, 0], xw[:, 0] = x[0], x[1]
+    for q, s_ in enumerate(cols):
+        xr[s_, 1 + 2 * q] = 1.0                # d / d r_s
+        xw[s_, 1 + 2 * q + 1] = 1.0            # d / d w_s
+    st, oagg, _ = orc.household_block(xr, xw, ss.value, ss.D, Nc)
+    assert st == 0
+    scale = np.max(np.abs(oagg[:, 1:1 + N]))
+    assert scale > 1e-3
+    for q, s_ in enumerate(cols):
+        assert np.max(np.abs(Jhh[0][:, s_] - oagg[:, 1 + 2 * q])) < 1e-8 * scale, ("r", s_)
+        assert np.max(np.abs(Jhh[1][:, s_] - oagg[:, 1 + 2 * q + 1])) < 1e-8 * scale, ("w", s_)
+
+
+def test_toeplitz_jacobian_on_the_reference_seven_columns_against_the_oracle(hank):
+    """test_SteadyState.jl:194-231's check — columns [1, 2, three seeded interior, n-1, n] of getSteadyStateJacobian against
+    JVP(fullPipelineFunc, x_ss, e_i) — with the ORACLE as the pipeline and 1e-8 of the largest entry instead of the
+    reference's abs 1e-5."""
+    m, ss, orc = ks_setup(50, 2, 100)
+    P = 99
+    n = 4 * P
+    J = hank.getSteadyStateJacobian(ss, m, method="toeplitz").toarray()
+    x0 = np.tile(np.array([ss.vars[k] for k in ("Y", "KS", "r", "w")])[:, None], (1, P))
+    Z = np.ones(P)
+    rng = np.random.default_rng(42)
+    cols = [0, 1, *rng.integers(2, n - 2, 3).tolist(), n - 2, n - 1]
+    Y = np.zeros((n, 8))
+    for q, c_ in enumerate(cols):
+        Y[c_, q] = 1.0
+    F_o, J_o = orc.ks_jvp(x0, Y.reshape(4, P, 8, order="F"), Z, m.params.α, m.params.δ, ss.vars["KS"], ss.value, ss.D)
+    assert np.max(np.abs(F_o)) < 1e-6                     # F(x_ss) = 0 through the full pipeline (SteadyState.jl:272-286), to the price Newton's tolerance
+    # 1e-8 of the largest response of the household block (d KD_t / d r_s, the entries the Toeplitz form computes; the equations'
+    # own entries are O(1)): the Toeplitz form takes the recorded steady state as exactly stationary, the oracle differentiates
+    # the path as it is (stationary to the value iteration's tolerance)
+    from hank_amd.SteadyStateJacobian import household_jacobian
+    from hank_amd.BackwardIteration import household_block
+    hb = household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(np.tile(np.array([[ss.vars["r"]], [ss.vars["w"]]]), (1, P)))
+    scale = max(np.max(np.abs(J)), np.max(np.abs(household_jacobian(*hb.fake_news()))))
+    for q, c_ in enumerate(cols):
+        assert np.max(np.abs(J[:, c_] - J_o[:, q])) < 1e-8 * scale, c_
