@@ -391,10 +391,11 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
     geom(VB, w.g); geom(VF, w.gf);
     w.nbx = w.g.nbx; w.nbxf = w.gf.nbx;
     const size_t GV = (size_t)(c.n_a + KV) * c.n_e;   // dD state carries KV virtual rows per column
-    // forward kernel form: source-stationary for 16-lane groups (N = 18..32: forward sweep 3.42 -> 3.05 ms at N=32
-    // with 2 row groups), target-stationary gather otherwise (equal within 2 % at N = 16, 64, 256)
+    // forward kernel form: source-stationary from 16-lane groups on (N >= 18: forward sweep 3.42 -> 3.05 ms at N=32 with 2 row
+    // groups; round 4, with the column index in a scalar register: 4.58 -> 4.28 ms at N=64, 12.5 -> 11.6 ms at N=256,
+    // profiles/r04_wide_knobs.log), target-stationary gather below
     const char *se = getenv("HANK_FWD_SS");   // dev knob
-    w.gf.ss = se ? atoi(se) : (w.gf.NC == 16 ? 1 : 0);
+    w.gf.ss = se ? atoi(se) : (w.gf.NC >= 16 ? 1 : 0);
     const int RGB = tan_rg(w.g.N, 0), RGF = tan_rg(w.gf.N, 1, w.gf.ss);
     const unsigned nbf = (w.nbxf + RGF - 1) / RGF + KV;   // forward blocks: regular + mass-point
     w.VB = VB; w.VF = VF; w.RGB = RGB; w.RGF = RGF; w.nbf = nbf;
@@ -474,7 +475,7 @@ static hipEvent_t g_xlast[64] = {};
 static size_t x_lds_primal_back(const Consts &c) { return sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * (size_t)c.P) + 64; }
 static size_t x_lds_tan_back(const Consts &c, int D) {
     const int SLt = D == 4 ? 6 : D;      // XTileT<D>::SL
-    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + c.P + 1 + 3 * (size_t)c.P * D) + sizeof(int) * (size_t)c.P + 64;
+    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + c.P + 1 + 3 * (size_t)c.P + 1 + 3 * (size_t)c.P * D) + sizeof(int) * (size_t)c.P + 64;
 }
 // k_xfwd with NSL live slots (the D partials + the value): tile, Pi, {source range, clamped prefix} and source members of every period
 static size_t x_lds_fwd(const Consts &c, int NSL) {
@@ -736,7 +737,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false) {
     const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
     const dim3 blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkF = blk;
     XTanBackArgs ab{};
-    ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st_ds = X.st_ds;
+    ab.c = c; ab.R = ctx->R; ab.rho = X.rho; ab.xhh = ctx->d_xhh; ab.dxr = w->dxr; ab.dxw = w->dxw; ab.dxt = w->dxt; ab.Ntot = N; ab.st_ds = X.st_ds;
     ab.src = neigh ? X.srcB : nullptr;
     ab.stall = X.fault == 3 ? 1 : 0;
     XSweepFwdArgs fa{};
@@ -858,6 +859,10 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     c.n_a = m->n_a; c.n_e = m->n_e; c.G = m->n_a * m->n_e; c.P = m->T - 1;
     c.beta = m->beta; c.gamma = m->gamma; c.bc = m->borrow_cons;
     c.n_hh = m->value_fn_id == HANK_VF_ONE_ASSET_HANK ? 3 : 2;
+    {   // record diet (hank_kernels.h:diet_kc): the tangent sweeps rebuild kc and v where CRRA's powers are products and a root
+        const char *rd = getenv("HANK_RECORD_DIET");      // dev knob (A-B): 0 = read kc and v from the record
+        c.diet = ((c.gamma == 1.0 || c.gamma == 2.0) && !(rd && atoi(rd) == 0)) ? 1 : 0;
+    }
     ctx->T = m->T;
     const size_t P = c.P, G = c.G;
     if ((2 * (size_t)c.n_a + 2) * sizeof(int) > 150 * 1024) return fail(ctx, HANK_ERR_BAD_ARG, "n_a=%d too large for the LDS-staged lottery", c.n_a);

@@ -24,6 +24,7 @@ constexpr int RBP = 32;        // rows (wealth points) per block in the primal k
 struct Consts {
     int n_a, n_e, G, P;
     int n_hh;   // household inputs per period: 2 = (r, w) Krusell-Smith; 3 = (r, w, tr) one-asset HANK (lump-sum transfer)
+    int diet;   // the tangent sweeps rebuild kc from s and v from u instead of reading them (CRRA with gamma = 1 or 2: see diet_kc)
     double beta, gamma, bc;
     const double *a, *z, *Pi;  // device
 };
@@ -146,6 +147,24 @@ __device__ __forceinline__ T mix_sum(T acc, const T *V, int vs, const double *P,
     return acc;
 }
 
+// RECORD DIET. Two of the seven coefficients a backward tangent step reads per point are functions of their neighbours in the
+// record: s = rho ((cm - (w z_e + tr)) + a) gives back cm, and kc = rho beta (-1/gamma) cm^(1 + gamma); u = cg^(-gamma) gives back
+// cg, and v = (1 + r)(-gamma) u / cg. With gamma = 1 or 2 the powers are products and one square root: 16 of the 52 bytes per
+// point and period are not read (by each of the 8 groups of a persistent sweep). Other gammas keep reading kc and v (a pow per
+// point, period and group costs more than the 16 bytes). Both implementations use these two functions, so their policy partials
+// stay bit-identical: the PRIMAL sweeps record kc and v as these two functions give them, the launch-path tangent kernels (whose
+// lane-sparse coefficient loads are off their critical path: rebuilding cost them 1-3 %) read the record, the persistent
+// tangent sweeps (8 groups re-read the record) rebuild: the same bits either way. Against the textbook expressions the values
+// move by rounding (cm is rebuilt through a cancellation: 1e-13).
+__device__ __forceinline__ double diet_kc(const Consts &c, double s, double rho, double opr, double wz_tr, double xa) {
+    const double cm = (s * opr + wz_tr) - xa;
+    const double k = rho * (c.beta * (-1.0 / c.gamma));
+    return c.gamma == 2.0 ? k * (cm * cm * cm) : k * (cm * cm);
+}
+__device__ __forceinline__ double diet_v(const Consts &c, double u, double opr) {
+    return c.gamma == 2.0 ? opr * (-2.0 * (u * sqrt(u))) : opr * (-(u * u));
+}
+
 // household inputs of period t: xhh[n_hh*t + k]; the lump-sum transfer is 0 for families without one
 __device__ __forceinline__ double hh_tr(const Consts &c, const double *xhh, int t) { return c.n_hh > 2 ? xhh[c.n_hh * t + 2] : 0.0; }
 
@@ -161,9 +180,11 @@ __device__ inline void egm_X(const Consts &c, const double *Vsh, const double *P
     if (pow_domain_error(bE, ex)) set_err(err, ERR_DOMAIN, t, e, a);
     const double cm = pow_crra(bE, ex);
     const double rho = 1.0 / (1.0 + r);
-    st_mode<HANK_ST_REC>(s_out, rho * ((cm - (w * c.z[e] + tr)) + c.a[a]));
-    // d cmat/dE = beta*ex*(bE)^(ex-1)  (Dual^Real, ForwardDiff dual.jl:563-572)
-    st_mode<HANK_ST_REC>(kc_out, rho * (c.beta * ex * (cm / bE)));
+    const double s1 = rho * ((cm - (w * c.z[e] + tr)) + c.a[a]);
+    st_mode<HANK_ST_REC>(s_out, s1);
+    // d cmat/dE = beta*ex*(bE)^(ex-1)  (Dual^Real, ForwardDiff dual.jl:563-572); under the record diet the recorded value IS the
+    // one the persistent tangent sweeps rebuild from s (diet_kc): whoever reads it and whoever rebuilds it hold the same bits
+    st_mode<HANK_ST_REC>(kc_out, c.diet ? diet_kc(c, s1, rho, 1.0 + r, w * c.z[e] + tr, c.a[a]) : rho * (c.beta * ex * (cm / bE)));
 }
 
 // Y half (KrusellSmith.jl:66-80): interpolate the policy on the exogenous grid point a from the
@@ -257,7 +278,7 @@ __device__ inline YOut egm_Y(const Consts &c, const KNOTS sc, int a, int e, doub
     o.B = B;
     o.ib = i;
     o.u = u;
-    o.v = opr * ((-c.gamma) * (u / cg));
+    o.v = c.diet ? diet_v(c, u, opr) : opr * ((-c.gamma) * (u / cg));
     o.V = opr * u;
     return o;
 }
@@ -642,6 +663,7 @@ __device__ inline void tan_back_body(const Consts &c, const Record &R, const dou
         if (c.n_hh > 2) { dtr = dxt[(size_t)t * N + n]; dtr1 = dxt[(size_t)txc * N + n]; }
     }
     const double ze = c.z[e], rho1 = 1.0 / (1.0 + xhh[c.n_hh * txc]);
+
     VT d0[RG], d1[RG];
 #pragma unroll
     for (int q = 0; q < RG; q++) {

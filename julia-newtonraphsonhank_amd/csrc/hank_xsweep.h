@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(MAXT) k_xprimal_back(XBackArgs A) {
                 const double cm = pow_crra(bE, ex);
                 const double rho = xsh[4 * tx + 3];             // 1/(1+r_tx), once per period (k_xrho), not once per thread
                 const double s1 = rho * ((cm - (xsh[4 * tx + 1] * ze + xsh[4 * tx + 2])) + xa);
-                const double kc = rho * (c.beta * ex * (cm / bE));
+                const double kc = c.diet ? diet_kc(c, s1, rho, 1.0 + xsh[4 * tx], xsh[4 * tx + 1] * ze + xsh[4 * tx + 2], xa) : rho * (c.beta * ex * (cm / bE));
                 sS[(size_t)(i & 1) * hs + pt] = s1;
                 A.R.s[(size_t)tx * G + pt] = s1; A.R.kc[(size_t)tx * G + pt] = kc;
             }
@@ -780,6 +780,7 @@ struct XTanBackArgs {
     Consts c;
     Record R;                   // s, kc, ib, A, B, u, v of the recorded primal
     const double *rho;          // [P] 1/(1+r_t)
+    const double *xhh;          // [n_hh*P] the household inputs of the recorded primal (record diet: see diet_kc)
     const double *dxr, *dxw, *dxt;
     int Ntot, n0, N;
     XSync *sy;
@@ -799,7 +800,8 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     double *tile = xl;                                  // [ne][64][SL]
     double *rhosh = tile + (size_t)SL * ne * 64;                    // [P]
-    double *dxsh = rhosh + ((P + 1) & ~1);                       // [P][3][D]: this group's dr, dw, dtr (a cold uniform load per period otherwise)
+    double *pxsh = rhosh + ((P + 1) & ~1);                       // [P][3]: 1 + r_t, w_t, tr_t (record diet)
+    double *dxsh = pxsh + 3 * (size_t)P + (P & 1);               // [P][3][D]: this group's dr, dw, dtr (a cold uniform load per period otherwise)
     int *srcsh = reinterpret_cast<int *>(dxsh + (size_t)P * 3 * D);      // [P]: this member's source ranges
     int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
@@ -810,6 +812,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
     for (int k = threadIdx.x; k < P; k += blockDim.x) rhosh[k] = A.rho[k];
+    for (int k = threadIdx.x; k < P; k += blockDim.x) { pxsh[3 * k] = 1.0 + A.xhh[c.n_hh * k]; pxsh[3 * k + 1] = A.xhh[c.n_hh * k + 1]; pxsh[3 * k + 2] = hh_tr(c, A.xhh, k); }
     for (int k = threadIdx.x; k < P; k += blockDim.x) srcsh[k] = A.src ? A.src[(size_t)k * Sact + cW] : ((Sact - 1) << 8);
     for (int k = threadIdx.x; k < P * D; k += blockDim.x) {
         const int t_ = k / D, d_ = k - t_ * D;
@@ -846,7 +849,7 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     // halves of the group barrier and land while the group meets
     int ibY = 0;
     double cA = 0.0, cB = 0.0, cu = 0.0, cv = 0.0, ck = 0.0, cs = 0.0;
-    if (own) { ck = R.kc[(size_t)(P - 1) * G + pt]; cs = R.s[(size_t)(P - 1) * G + pt]; }
+    if (own) { cs = R.s[(size_t)(P - 1) * G + pt]; if (!c.diet) ck = R.kc[(size_t)(P - 1) * G + pt]; }
     // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0); member c publishes episode i+1 when the stores of trip i have drained
     const int son = (x == 0 && cW < 32) ? cW : -1;     // dev stamps (make stamp)
     (void)son;
@@ -870,11 +873,12 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
                     rows.load(rb + ibY, d0);
                     rows.load(rb + ibY + 1, d1);
                 }
+                const double cvt = c.diet ? diet_v(c, cu, pxsh[3 * t]) : cv;
 #pragma unroll
                 for (int k = 0; k < D; k++) {
                     const double dr = dxsh[(t * 3 + 0) * D + k], dw = dxsh[(t * 3 + 1) * D + k], dtr = dxsh[(t * 3 + 2) * D + k];
                     dg[k] = cA * d0[k] + cB * d1[k];
-                    dV[k] = cu * dr + cv * ((xa * dr + (ze * dw + dtr)) - dg[k]);
+                    dV[k] = cu * dr + cvt * ((xa * dr + (ze * dw + dtr)) - dg[k]);
                 }
                 xstore_row<D>(A.dpol + (((size_t)t * A.groups + x) * G + pt) * D, dg);
             }
@@ -890,12 +894,13 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
             const int tx = P - 1 - i;
             if (own) {
                 const double rho = rhosh[tx];
+                const double ckt = c.diet ? diet_kc(c, cs, rho, pxsh[3 * tx], pxsh[3 * tx + 1] * ze + pxsh[3 * tx + 2], xa) : ck;
                 double mx[D], ds[D];
                 xtile_mix_reg<SL, D>(tile + (size_t)lane * SL, pr, ne, mx);
 #pragma unroll
                 for (int k = 0; k < D; k++) {
                     const double dr1 = dxsh[(tx * 3 + 0) * D + k], dw1 = dxsh[(tx * 3 + 1) * D + k], dt1 = dxsh[(tx * 3 + 2) * D + k];
-                    ds[k] = ck * mx[k] - rho * ((ze * dw1 + dt1) + cs * dr1);
+                    ds[k] = ckt * mx[k] - rho * ((ze * dw1 + dt1) + cs * dr1);
                 }
                 rows.store((size_t)(i & 1) * hs + gx + pt, ds);
             }
@@ -905,8 +910,9 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
             if (sync_duty && !(A.stall && x == 0 && cW == 0 && i > 2)) xpublish(A.sy, x, cW, (unsigned)(i + 1));
             if (own) {      // the record the next trip needs (Y of period tx, X of period tx - 1): in flight while the others arrive
                 const size_t ro = (size_t)tx * G + pt;
-                ibY = R.ib[ro]; cA = R.A[ro]; cB = R.B[ro]; cu = R.u[ro]; cv = R.v[ro];
-                if (tx > 0) { ck = R.kc[ro - G]; cs = R.s[ro - G]; }
+                ibY = R.ib[ro]; cA = R.A[ro]; cB = R.B[ro]; cu = R.u[ro];
+                if (!c.diet) cv = R.v[ro];
+                if (tx > 0) { cs = R.s[ro - G]; if (!c.diet) ck = R.kc[ro - G]; }
             }
         }
     }
