@@ -18,10 +18,11 @@ from oracle.oracle import pad_N  # noqa: E402
 
 
 def block(m, schedule):
-    os.environ["HANK_SCHEDULE"] = schedule
+    if schedule != "auto":
+        os.environ["HANK_SCHEDULE"] = schedule
     wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
     hb = h.HouseholdBlock(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T)
-    os.environ.pop("HANK_SCHEDULE")
+    os.environ.pop("HANK_SCHEDULE", None)
     return hb
 
 
@@ -116,6 +117,8 @@ if __name__ == "__main__":
         timing(2000, 11, 300, [32, 64], scheds=("launch",))
     if what == "tl":      # the launched sweeps alone
         timing(2000, 11, 300, [16, 32, 64, 128, 256], scheds=("launch",))
+    if what == "ta":      # the default schedule (what bench.py times)
+        timing(2000, 11, 300, [1, 8, 16, 32, 36, 64], scheds=("auto",))
     if what == "tx":      # the persistent sweeps alone, the widths that matter
         timing(2000, 11, 300, [1, 16, 32, 64], scheds=("xcd",))
     if what in ("all", "time"):
