@@ -44,6 +44,7 @@ def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False
     J = h.getSteadyStateJacobian(ss, m, method=jacobian)
     t_jac = time.perf_counter() - t0
     h.y_Iteration.total_jvps = 0
+    h.y_Iteration.setup_s = 0.0
     t0 = time.perf_counter()
     x = h.NewtonRaphsonHANK(x0, J, {"ei": ei}, m, ss, ss, ε=eps, verbose=verbose, inner=inner)
     t_newton = time.perf_counter() - t0
@@ -51,7 +52,8 @@ def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False
     X = x.reshape(len(keys), P, order="F")
     out = {"model": "one-asset HANK", "grid": f"{n_a}x{n_e}", "T": T, "shock": f"ei_t = {shock}*{rho}^(t-1)",
            "B": m.params.B, "calibrate_and_steady_state_s": round(t_ss, 3), "ss_jacobian_s": round(t_jac, 3),
-           "newton_s": round(t_newton, 3), "newton_iterations": h.NewtonRaphsonHANK.iterations,
+           "newton_s": round(t_newton, 3), "preconditioner_setup_s": round(h.y_Iteration.setup_s, 3),      # (inside newton_s: J̅⁻¹ on the device, once per J̅)
+           "newton_iterations": h.NewtonRaphsonHANK.iterations,
            "jvps": h.y_Iteration.total_jvps, "residual_norm": float(np.linalg.norm(lin.Fx)),
            "wall_to_converged_path_s": round(t_jac + t_newton, 3), "inner": inner, "jacobian": jacobian,
            "impact": {k: float(X[j, 0] - ss.vars[k]) for j, k in enumerate(keys)}}

@@ -42,12 +42,13 @@ def solve(n_a=500, n_e=4, T=300, shock=0.01, eps=1e-9, verbose=False, cold=False
     J = h.getSteadyStateJacobian(ss, m, method=jacobian)
     t_jac = time.perf_counter() - t0
     h.y_Iteration.total_jvps = 0
+    h.y_Iteration.setup_s = 0.0
     t0 = time.perf_counter()
     x = h.NewtonRaphsonHANK(x0, J, {"Z": Z}, m, ss, ss, ε=eps, verbose=verbose, inner=inner)
     t_newton = time.perf_counter() - t0
     lin = h.LinearizedFunction(x, {"Z": Z}, m, ss, ss)
     return {"grid": f"{n_a}x{n_e}", "T": T, "shock": f"Z_t = 1 + {shock}*0.8^t", "steady_state_s": round(t_ss, 3),
-            "ss_jacobian_s": round(t_jac, 3), "newton_s": round(t_newton, 3),
+            "ss_jacobian_s": round(t_jac, 3), "newton_s": round(t_newton, 3), "preconditioner_setup_s": round(h.y_Iteration.setup_s, 3),
             "newton_iterations": h.NewtonRaphsonHANK.iterations, "jvps": h.y_Iteration.total_jvps, "residual_norm": float(np.linalg.norm(lin.Fx)),
             "wall_to_converged_path_s": round(t_jac + t_newton, 3), "steady_state": "cold start" if cold else "cached",
             "inner": inner, "jacobian": jacobian}, x

@@ -187,9 +187,15 @@ def _device_inverse_solver(J):
     except Exception:       # noqa: BLE001
         return None
     if not (_INV_CACHE and _INV_CACHE[0][0] is J):
+        import time
+        t0 = time.perf_counter()
         A = J.toarray() if hasattr(J, "toarray") else np.asarray(J)
         dev = torch.device("cuda", torch.cuda.current_device())
         Ainv = torch.linalg.inv(torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(dev))
+        (Ainv[:1] @ Ainv[:, :1]).cpu()      # the first product of a process also loads rocBLAS: count it with the set-up, not with an iteration
+        # once per J̅ (and, the first time in a process, the linear-algebra libraries' own start-up: 0.15-0.35 s against 40 ms warm at
+        # n = 3 493, scripts/dev_inv_cost.py): reported next to the solve times, examples/solve_hank.py
+        y_Iteration.setup_s = getattr(y_Iteration, "setup_s", 0.0) + (time.perf_counter() - t0)
 
         def apply(b, Ainv=Ainv, dev=dev):
             return (Ainv @ torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).to(dev)).cpu().numpy()
