@@ -311,14 +311,16 @@ def self_launch(args, argv):
     BEFORE this process has made any GPU call (it never makes one), relay rank 0's JSON line, and fail if any rank fails.
     Children are started, never exec'ed into: no process that has touched a GPU is replaced."""
     import subprocess
+    import tempfile
     port = _free_port()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")        # rank 0's stdout (a file, not a pipe: nobody reads it while the ranks run)
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env, cwd=str(ROOT),
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
     # a rank that dies leaves the others in a collective: watch all of them, end the rest when one fails
     failed = None
     while failed is None and any(p.poll() is None for p in procs):
@@ -337,8 +339,8 @@ def self_launch(args, argv):
                 p.kill()
         print(f"bench.py: rank {failed[0]} of {args.gpus} exited with status {failed[1]}", file=sys.stderr)
         return 1
-    out = procs[0].stdout.read()
-    lines = [l for l in out.splitlines() if l.startswith("{")]
+    out0.seek(0)
+    lines = [l for l in out0.read().splitlines() if l.startswith("{")]
     if not lines:
         print("bench.py: rank 0 printed no result line", file=sys.stderr)
         return 1
