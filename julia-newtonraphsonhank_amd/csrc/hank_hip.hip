@@ -128,6 +128,7 @@ struct hank_ctx {
     // primal memo of the host-pointer hank_primal_jvp (NewtonRaphson.jl:91-95 calls JVP(fullFunction, x, y) ~21 times at one x):
     // the x whose linearisation is on record, as the host handed it in
     bool memo_on = true;                              // HANK_PRIMAL_MEMO=0 (read at hank_create) switches it off
+    bool xdual_back = true;                           // dev knob HANK_XDUAL_BACK=0 (read at hank_create): a persistent Dual pass runs k_xprimal_back + k_xtan_back instead of k_xdual_back
     bool memo_valid = false;
     std::vector<double> memo_xhh;
     bool stationary = false;                          // the recorded primal is the constant steady-state path with the steady state as both boundaries (hank_fake_news)
@@ -477,6 +478,11 @@ static size_t x_lds_tan_back(const Consts &c, int D) {
     const int SLt = D == 4 ? 6 : D;      // XTileT<D>::SL
     return sizeof(double) * ((size_t)SLt * c.n_e * 64 + c.P + 1 + 3 * (size_t)c.P + 1 + 3 * (size_t)c.P * D) + sizeof(int) * (size_t)c.P + 64;
 }
+// k_xdual_back<D>: tile of D + 1 slots, Pi, the grid, the household inputs and this group's input tangents of every period
+static size_t x_lds_dual_back(const Consts &c, int D) {
+    const int NSL = D + 1, SLt = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);
+    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + 1 + c.n_a + 1 + 4 * (size_t)c.P + 3 * (size_t)c.P * D) + 64;
+}
 // k_xfwd with NSL live slots (the D partials + the value): tile, Pi, {source range, clamped prefix} and source members of every period
 static size_t x_lds_fwd(const Consts &c, int NSL) {
     const int SLt = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);      // XSlots<NSL>::SL
@@ -614,6 +620,12 @@ static void x_launch_tan_back(int D, dim3 grd, dim3 blk, size_t lds, hipStream_t
     else if (D == 4) { if constexpr (MAXT == 768) hipLaunchKernelGGL((k_xtan_back<4, MAXT>), grd, blk, lds, s, ab); }
 }
 
+static void x_launch_dual_back(int D, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XDualBackArgs &ab) {
+    if (D == 1) hipLaunchKernelGGL((k_xdual_back<1, 768>), grd, blk, lds, s, ab);
+    else if (D == 2) hipLaunchKernelGGL((k_xdual_back<2, 768>), grd, blk, lds, s, ab);
+    else hipLaunchKernelGGL((k_xdual_back<4, 768>), grd, blk, lds, s, ab);
+}
+
 // k_xfwd<D, VAL>: D = 0 (the Float64 sweep alone, VAL), 1, 2, 4
 template <int MAXT>
 static void x_launch_fwd(int D, bool val, dim3 grd, dim3 blk, size_t lds, hipStream_t s, const XSweepFwdArgs &a) {
@@ -659,7 +671,9 @@ static int x_sync_reset(hank_ctx *ctx, XSync *base, int count, int where) {     
 // the Float64 recurrences at the context's current x (d_xhh) and boundary: two persistent launches on ONE XCD's
 // workgroups (the policy sequence, the distribution path and the linearisation record the tangent sweeps read)
 // skip_fwd: the distribution sweep travels with the tangents' forward sweep instead (k_xfwd<D, true>, x_run_tangent(.., val))
-static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false) {
+// dual: the backward sweep carries the partials of this ONE-pass batch too (k_xdual_back; implies skip_fwd — the caller follows
+// with x_run_tangent(.., val, skip_back))
+static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullptr) {
     XWork &X = ctx->xw;
     const Consts &c = ctx->c;
     const size_t P = c.P;
@@ -670,6 +684,7 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
     hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
+    if (dual) hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * dual->N + 255) / 256)), dim3(256), 0, s, dual->dxhh, c.n_hh, (int)P, dual->N, dual->dxr, dual->dxw, dual->dxt);
     // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
     const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
     const dim3 grd(X.grid), blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkf = blk;
@@ -678,7 +693,13 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false) {
     ab.err = ctx->d_err; ab.R = ctx->R;
     const size_t ldsb = x_lds_primal_back(c);
     HIPC(ctx, hipEventRecord(ctx->ev[0], s));
-    if (X.maxt == 768) hipLaunchKernelGGL((k_xprimal_back<768>), grd, blk, ldsb, s, ab);
+    if (dual) {
+        const XPass &ps = dual->passes[0];
+        XDualBackArgs db{};
+        db.p = ab; db.dxr = dual->dxr; db.dxw = dual->dxw; db.dxt = dual->dxt; db.Ntot = dual->N; db.n0 = ps.n0; db.N = ps.N;
+        db.st_ds = X.st_ds; db.dpol = dual->dpol + ps.dpol_off; db.groups = ps.groups;
+        x_launch_dual_back(ps.D, grd, blk, x_lds_dual_back(c, ps.D), s, db);
+    } else if (X.maxt == 768) hipLaunchKernelGGL((k_xprimal_back<768>), grd, blk, ldsb, s, ab);
     else hipLaunchKernelGGL((k_xprimal_back<1024>), grd, blk, ldsb, s, ab);
     HIPC(ctx, hipEventRecord(ctx->ev[1], s));
     hipLaunchKernelGGL(k_lottery, dim3((unsigned)(P * c.n_e)), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
@@ -713,7 +734,8 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false) {
 
 // the N partials of `w` at the recorded primal: two persistent launches per pass of up to 8*dmax directions, every XCD a group
 // val: the first pass's forward sweep carries the value too (the Float64 distribution sweep of a Dual pass) and writes the record
-static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false) {
+// skip_back: the backward sweep of this (one-pass) batch has run with the Float64 sweep (k_xdual_back, x_run_primal(.., dual))
+static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_back = false) {
     XWork &X = ctx->xw;
     const Consts &c = ctx->c;
     const size_t P = c.P;
@@ -724,9 +746,9 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false) {
     // sync blocks 0, 1 belong to the primal sweeps (their status is checked with this call's when both ran unchecked)
     rc = x_sync_reset(ctx, X.sync + 2, 2 * np, 2);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
-    hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);     // (the primal may have been recorded by the launches)
-    if (!X.src_valid) {      // once per recorded primal: which members each member's gathers read, period by period
+    if (!skip_back) hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
+    if (!skip_back) hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);     // (the primal may have been recorded by the launches)
+    if (!X.src_valid && !skip_back) {      // once per recorded primal: which members each member's gathers read, period by period
         hipLaunchKernelGGL(k_xsrc_back, dim3((unsigned)P, X.Sact), dim3(256), 0, s, c, ctx->R, X.Sact, X.srcB);
         X.src_valid = true;
     }
@@ -743,7 +765,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false) {
     XSweepFwdArgs fa{};
     fa.c = c; fa.R = ctx->R; fa.st = X.st_dD; fa.daggpart = w->daggpart; fa.src = X.srcF; fa.units = X.unitsF; fa.all_members = neigh ? 0 : 1;
     HIPC(ctx, hipEventRecord(ctx->ev[3], s));
-    for (int p = 0; p < np; p++) {
+    for (int p = 0; p < np && !skip_back; p++) {
         const XPass &ps = w->passes[p];
         ab.n0 = ps.n0; ab.N = ps.N; ab.groups = ps.groups; ab.sy = X.sync + 2 + 2 * p; ab.dpol = w->dpol + ps.dpol_off;
         const size_t lds = x_lds_tan_back(c, ps.D);
@@ -914,6 +936,7 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     }
     if (const char *xm = getenv("HANK_XJVP_MAX")) ctx->xjvp_max = atoi(xm);
     if (const char *pm = getenv("HANK_PRIMAL_MEMO")) ctx->memo_on = atoi(pm) != 0;
+    if (const char *xd = getenv("HANK_XDUAL_BACK")) ctx->xdual_back = atoi(xd) != 0;
     int rc = HANK_OK;
     if (ctx->schedule == 0) rc = build_primal_graphs(ctx);
     else rc = x_setup(ctx);
@@ -1052,13 +1075,17 @@ static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcp
     rc = x_ensure_tan(ctx, N, &w);
     if (rc) return rc;
     const size_t P = ctx->c.P;
+    // a Dual pass of one pass (N <= 8 groups x 4): value and partials together in BOTH sweeps (k_xdual_back, k_xfwd<D, true>)
+    const XWork &X = ctx->xw;
+    const bool fused_back = xhh && ctx->xdual_back && w->passes.size() == 1 && X.maxt == 768 && 64 * (ctx->c.n_e + 1) <= X.maxt &&
+                            x_lds_dual_back(ctx->c, w->passes[0].D) <= (size_t)X.lds_max;
+    HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
     if (xhh) {
         HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, kind, ctx->stream));
-        rc = x_run_primal(ctx, true);        // the distribution sweep rides on the tangents' forward sweep (value + partials)
+        rc = x_run_primal(ctx, true, fused_back ? w : nullptr);        // the distribution sweep rides on the tangents' forward sweep (value + partials)
         if (rc) return rc;
     }
-    HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
-    rc = x_run_tangent(ctx, w, xhh != nullptr);
+    rc = x_run_tangent(ctx, w, xhh != nullptr, fused_back);
     if (rc) return rc;
     if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
     if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, w->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));

@@ -137,27 +137,38 @@ struct XGroup { int x, c, S, ok; };
 // dev build only (make stamp): s_memtime stamps of lane 0 / wave 0 of the first and last member of group 0, periods
 // [XSTAMP_T0, XSTAMP_T0+8): where a period's time goes. Never compiled into the product library.
 #ifdef HANK_XSTAMP
-constexpr int XSTAMP_T0 = 100, XSTAMP_NP = 8, XSTAMP_NS = 12;
+#ifndef HANK_XSTAMP_T0
+#define HANK_XSTAMP_T0 100
+#endif
+#ifndef HANK_XSTAMP_STRIDE
+#define HANK_XSTAMP_STRIDE 1       // > 1: every STRIDE-th period from T0 on is stamped (where in the sweep the time goes)
+#endif
+constexpr int XSTAMP_T0 = HANK_XSTAMP_T0, XSTAMP_NP = 8, XSTAMP_NS = 12, XSTAMP_ST = HANK_XSTAMP_STRIDE;
+#define XSTAMP_ON(per) ((per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP * XSTAMP_ST && ((per) - XSTAMP_T0) % XSTAMP_ST == 0)
+#define XSTAMP_SLOT(per) (((per) - XSTAMP_T0) / XSTAMP_ST)
 __device__ unsigned long long g_xstamps[2][32][XSTAMP_NP][XSTAMP_NS];     // [sweep][member of group 0][period][stamp]
 #define XSTAMP(sw, on, per, i)                                                                                   \
     do {                                                                                                         \
-        if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && threadIdx.x == 0)                 \
-            g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memrealtime();                              \
+        if ((on) >= 0 && XSTAMP_ON(per) && threadIdx.x == 0)                 \
+            g_xstamps[sw][on][XSTAMP_SLOT(per)][i] = __builtin_amdgcn_s_memrealtime();                              \
     } while (0)
 // stamp taken by lane 0 of wave `wave` (arrival of the other waves at a workgroup barrier)
 #define XSTAMPW(sw, on, per, i, wave)                                                                            \
     do {                                                                                                         \
-        if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (int)threadIdx.x == 64 * (wave))  \
-            g_xstamps[sw][on][(per) - XSTAMP_T0][i] = __builtin_amdgcn_s_memrealtime();                              \
+        if ((on) >= 0 && XSTAMP_ON(per) && (int)threadIdx.x == 64 * (wave))  \
+            g_xstamps[sw][on][XSTAMP_SLOT(per)][i] = __builtin_amdgcn_s_memrealtime();                              \
     } while (0)
 // every wave's arrival at one chosen point of the period (lane 0 of each wave)
 __device__ unsigned long long g_xwaves[2][32][XSTAMP_NP][16];
 #define XSTAMPV(sw, on, per)                                                                                     \
     do {                                                                                                         \
-        if ((on) >= 0 && (per) >= XSTAMP_T0 && (per) < XSTAMP_T0 + XSTAMP_NP && (threadIdx.x & 63) == 0)          \
-            g_xwaves[sw][on][(per) - XSTAMP_T0][threadIdx.x >> 6] = __builtin_amdgcn_s_memrealtime();             \
+        if ((on) >= 0 && XSTAMP_ON(per) && (threadIdx.x & 63) == 0)          \
+            g_xwaves[sw][on][XSTAMP_SLOT(per)][threadIdx.x >> 6] = __builtin_amdgcn_s_memrealtime();             \
     } while (0)
+// once per kernel (entry, prologue done, loop done): slot 0, stamps 9..11
+#define XSTAMP1(sw, on, i) do { if ((on) >= 0 && threadIdx.x == 0) g_xstamps[sw][on][0][i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define XSTAMP1(sw, on, i) do {} while (0)
 #define XSTAMPV(sw, on, per) do {} while (0)
 #define XSTAMP(sw, on, per, i) do {} while (0)
 #define XSTAMPW(sw, on, per, i, wave) do {} while (0)
@@ -352,6 +363,27 @@ __device__ __forceinline__ void xtile_mix(const double *tl, const double *P, int
         const double p = P[k * ps];
 #pragma unroll
         for (int q = 0; q < NS; q++) out[q] = k == 0 ? p * v[q] : out[q] + p * v[q];
+    }
+}
+
+// the same arithmetic with the 16 steps unrolled (the ones beyond n_e predicated off), coefficients from LDS: every tile read of
+// the pass is in flight at once and no register holds a coefficient
+template <int SL, int NS>
+__device__ __forceinline__ void xtile_mix_flat(const double *tl, const double *P, int ps, int ne, double *out) {
+    const int ks = 64 * SL;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < ne) {
+            double v[SL];
+            if (SL == 1) v[0] = tl[(size_t)k * ks];
+            else {
+#pragma unroll
+                for (int q = 0; q < (NS + 1) / 2; q++) { const double2 d = reinterpret_cast<const double2 *>(tl + (size_t)k * ks)[q]; v[2 * q] = d.x; v[2 * q + 1] = d.y; }
+            }
+            const double p = P[k * ps];
+#pragma unroll
+            for (int q = 0; q < NS; q++) out[q] = k == 0 ? p * v[q] : out[q] + p * v[q];
+        }
     }
 }
 
@@ -918,6 +950,197 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     }
 }
 
+// slots of a sweep that carries NSL numbers per grid point (the D partials and, in a Dual pass, the value)
+template <int NSL> struct XSlots {
+    static constexpr int SP = NSL == 1 ? 1 : ((NSL + 1) / 2) * 2;        // slots of a state row (planes of 16-byte pairs)
+    static constexpr int SL = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);      // slots of a tile entry (see XTileT)
+};
+
+// ---- the backward half of a Dual pass (hank_primal_jvp) as ONE launch: value AND D partials in every group -----------
+// Every group repeats the Float64 EGM step (bit for bit the same in all of them: same expressions, same order) and carries
+// its own D partials through it. What that buys over k_xprimal_back followed by k_xtan_back: one chain of P periods instead
+// of two, and the tangent half never reads the record — the bracket and the coefficients of a row are the registers of the
+// lane that has just computed them. What it costs: the EGM step's arithmetic in all eight groups at once (it is parallel,
+// not serial: every XCD would otherwise idle behind XCD 0) and the partials' gather behind the bracket search instead of
+// behind a prefetched bracket. The record and the policy for every later hank_jvp at this primal are written once, the arrays shared out over the groups (all hold the same numbers). The value
+// rides as one more slot of the partials' LDS tile (slot D), so one pass over the columns mixes all of them.
+struct XDualBackArgs {
+    XBackArgs p;                // the Float64 sweep's arguments (st_s: [2][XG][G], a slice per group here)
+    const double *dxr, *dxw, *dxt;
+    int Ntot, n0, N;
+    double *st_ds;              // [2][XG][G][D]
+    double *dpol;               // [P][groups][G][D]
+    int groups;
+};
+
+template <int D, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_xdual_back(XDualBackArgs B) {
+    constexpr int NSL = D + 1, SL = XSlots<NSL>::SL, IV = D;
+    extern __shared__ __attribute__((aligned(16))) double xl[];
+    const XBackArgs &A = B.p;
+    const Consts &c = A.c;
+    const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
+    double *tile = xl;                                  // [ne][64][SL]: slots 0..D-1 the partials of V, slot D the value
+    double *Pish = tile + (size_t)SL * ne * 64;         // [ne*ne]
+    double *ash = Pish + ((ne * ne + 1) & ~1);          // [na]
+    double *xsh = ash + ((na + 1) & ~1);                // [P][4]: r_t, w_t, tr_t, rho_t
+    double *dxsh = xsh + 4 * (size_t)P;                 // [P][3][D]: this group's dr, dw, dtr
+    int *ctl = reinterpret_cast<int *>(dxsh + (size_t)P * 3 * D);
+#ifdef HANK_XSTAMP
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+    const XGroup g = xgroup_join(A.sy, ctl);
+    if (!g.ok) return;
+    const int x = g.x, cW = g.c;
+    if (x >= B.groups) return;
+    const int Sact = (na + XRW - 1) / XRW;
+    if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
+    if (cW >= Sact) return;
+    const int son = (x == 0 && cW < 32) ? cW : -1;     // dev stamps (make stamp)
+    (void)son;
+#ifdef HANK_XSTAMP
+    if (son >= 0 && threadIdx.x == 0) g_xstamps[0][son][0][8] = t_entry;
+#endif
+    XSTAMP1(0, son, 9);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool syncw = wv >= ne;
+    const bool sync_duty = blockDim.x > 64 * ne ? syncw : wv == 0;
+    const int e = syncw ? 0 : wv;
+    const int a = cW * XRW + lane;
+    const bool own = !syncw && lane < XRW && a < na;
+    // every group holds the same Float64 numbers: group x writes the record arrays j with j % groups == x (pol, ib, A, B, u, v, s, kc)
+    const int ng = B.groups;
+    const bool rc0 = 0 % ng == x, rc1 = 1 % ng == x, rc2 = 2 % ng == x, rc3 = 3 % ng == x, rc4 = 4 % ng == x, rc5 = 5 % ng == x, rc6 = 6 % ng == x, rc7 = 7 % ng == x;
+    const size_t pt = (size_t)e * na + (own ? a : 0);
+    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
+    for (int k = threadIdx.x; k < na; k += blockDim.x) ash[k] = c.a[k];
+    for (int k = threadIdx.x; k < P; k += blockDim.x) {
+        xsh[4 * k] = A.xhh[c.n_hh * k]; xsh[4 * k + 1] = A.xhh[c.n_hh * k + 1]; xsh[4 * k + 2] = hh_tr(c, A.xhh, k); xsh[4 * k + 3] = A.rho[k];
+    }
+    for (int k = threadIdx.x; k < P * D; k += blockDim.x) {
+        const int t_ = k / D, d_ = k - t_ * D;
+        const bool on = x * D + d_ < B.N;
+        const size_t ix = (size_t)t_ * B.Ntot + B.n0 + x * D + d_;
+        dxsh[(t_ * 3 + 0) * D + d_] = on ? B.dxr[ix] : 0.0;
+        dxsh[(t_ * 3 + 1) * D + d_] = on ? B.dxw[ix] : 0.0;
+        dxsh[(t_ * 3 + 2) * D + d_] = (on && c.n_hh > 2) ? B.dxt[ix] : 0.0;
+    }
+    Consts cl = c;
+    cl.a = ash;
+    const double ze = c.z[e], xa = c.a[own ? a : 0];
+    const size_t hs = (size_t)XG * G, gx = (size_t)x * G;
+    double *const sS = A.st_s;
+    XRows<D> rows;
+    rows.init(B.st_ds, 2 * hs);
+    double *const myt = tile + ((size_t)e * 64 + lane) * SL;
+    if (!syncw) {
+        double z[NSL];
+#pragma unroll
+        for (int k = 0; k < D; k++) z[k] = 0.0;         // dV_T = 0, V_T = the terminal marginal value (BackwardIteration.jl:85)
+        z[IV] = own ? A.ss_value[pt] : 0.0;
+        xtile_store_n<SL, NSL>(myt, z);
+    }
+    __syncthreads();
+    int guess = -1;
+    unsigned episode = 0;
+    XSTAMP1(0, son, 10);
+    // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0), one group barrier after every X (as k_xprimal_back)
+    for (int i = 0; i <= P; i++) {
+        XSTAMP(0, son, i, 0);
+        if (i > 0) {
+            const int t = P - i, cur = (i - 1) & 1;
+            double tv[NSL];
+#pragma unroll
+            for (int k = 0; k < NSL; k++) tv[k] = 0.0;
+            if (own) {
+                XKnots kn;
+                kn.preload(sS + (size_t)cur * hs + gx + (size_t)e * na, a, na, guess);
+                // the partials' rows at the bracket of the period before, in the same batch of loads as the knots: the bracket
+                // rarely moves by more than a knot per period, and behind the search every gather is a round trip of its own
+                const size_t rb = (size_t)cur * hs + gx + (size_t)e * na;
+                const int q = guess < 0 ? 0 : (guess < na - 1 ? guess : na - 2);
+                double w0[D], w1[D];
+                rows.load(rb + q, w0);
+                rows.load(rb + q + 1, w1);
+                const YOut o = egm_Y(cl, kn, a, e, xsh[4 * t], xsh[4 * t + 1], xsh[4 * t + 2], A.err, t, guess);
+                guess = o.ib;
+                tv[IV] = o.V;
+                XSTAMP(0, son, i, 1);
+                // Y-tangent (k_xtan_back's expressions; the coefficients are this lane's own)
+                double d0[D], d1[D], dg[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) d0[k] = d1[k] = 0.0;
+                if (o.A != 0.0 || o.B != 0.0) {
+                    if (o.ib == q) {
+#pragma unroll
+                        for (int k = 0; k < D; k++) { d0[k] = w0[k]; d1[k] = w1[k]; }
+                    } else if (o.ib == q + 1) {
+#pragma unroll
+                        for (int k = 0; k < D; k++) d0[k] = w1[k];
+                        rows.load(rb + o.ib + 1, d1);
+                    } else if (o.ib == q - 1) {
+#pragma unroll
+                        for (int k = 0; k < D; k++) d1[k] = w0[k];
+                        rows.load(rb + o.ib, d0);
+                    } else {
+                        rows.load(rb + o.ib, d0);
+                        rows.load(rb + o.ib + 1, d1);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    const double dr = dxsh[(t * 3 + 0) * D + k], dw = dxsh[(t * 3 + 1) * D + k], dtr = dxsh[(t * 3 + 2) * D + k];
+                    dg[k] = o.A * d0[k] + o.B * d1[k];
+                    tv[k] = o.u * dr + o.v * ((xa * dr + (ze * dw + dtr)) - dg[k]);
+                }
+                xstore_row<D>(B.dpol + (((size_t)t * B.groups + x) * G + pt) * D, dg);
+                const size_t ro = (size_t)t * G + pt;
+                if (rc0) A.R.pol[ro] = o.g;
+                if (rc1) A.R.ib[ro] = o.ib;
+                if (rc2) A.R.A[ro] = o.A;
+                if (rc3) A.R.B[ro] = o.B;
+                if (rc4) A.R.u[ro] = o.u;
+                if (rc5) A.R.v[ro] = o.v;
+            }
+            if (!syncw) xtile_store_n<SL, NSL>(myt, tv);
+            XSTAMP(0, son, i, 2);
+            XSTAMPV(0, son, i);
+            xlds_barrier();
+            XSTAMP(0, son, i, 3);
+        }
+        if (i < P) {
+            const int tx = P - 1 - i;
+            if (own) {
+                double mx[NSL];
+                xtile_mix_flat<SL, NSL>(tile + (size_t)lane * SL, Pish + e, ne, ne, mx);
+                const double bE = mx[IV] * c.beta;
+                const double ex = -1.0 / c.gamma;
+                if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);
+                const double cm = pow_crra(bE, ex);
+                const double rho = xsh[4 * tx + 3];
+                const double s1 = rho * ((cm - (xsh[4 * tx + 1] * ze + xsh[4 * tx + 2])) + xa);
+                const double kc = c.diet ? diet_kc(c, s1, rho, 1.0 + xsh[4 * tx], xsh[4 * tx + 1] * ze + xsh[4 * tx + 2], xa) : rho * (c.beta * ex * (cm / bE));
+                double ds[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    const double dr1 = dxsh[(tx * 3 + 0) * D + k], dw1 = dxsh[(tx * 3 + 1) * D + k], dt1 = dxsh[(tx * 3 + 2) * D + k];
+                    ds[k] = kc * mx[k] - rho * ((ze * dw1 + dt1) + s1 * dr1);
+                }
+                sS[(size_t)(i & 1) * hs + gx + pt] = s1;
+                rows.store((size_t)(i & 1) * hs + gx + pt, ds);
+                if (rc6) A.R.s[(size_t)tx * G + pt] = s1;
+                if (rc7) A.R.kc[(size_t)tx * G + pt] = kc;
+            }
+            episode++;
+            XSTAMP(0, son, i, 4);
+            xbar_arrive(!syncw);
+            XSTAMP(0, son, i, 5);
+            xbar_wait(A.sy, x, cW, Sact, episode, sync_duty);
+        }
+    }
+    XSTAMP1(0, son, 11);
+}
+
 // ================================ forward sweeps, source-stationary (round 4) ========================================
 // ONE kernel for the three forward recurrences (ForwardIteration.jl:297-308 and its partials):
 //   k_xfwd<0, true>  the Float64 distribution sweep: group 0 only, writes D_1..D_P, {w, ig D} and the aggregate
@@ -937,10 +1160,6 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
 // The mass kept on the members' virtual rows travels as extra lanes of the unit that walks source row 0 of an open column
 // (same lottery record, the members' virtual rows as state rows): no special sums. The mass point itself needs no load at
 // all: a member's clamped rows and its virtual row are its own rows of the previous period — its own registers.
-template <int NSL> struct XSlots {
-    static constexpr int SP = NSL == 1 ? 1 : ((NSL + 1) / 2) * 2;        // slots of a state row (planes of 16-byte pairs)
-    static constexpr int SL = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);      // slots of a tile entry (see XTileT)
-};
 constexpr int XUCAP = 64;       // work units per member and period (k_xunits_fwd reports an overflow; the host then uses the launches)
 struct XSweepFwdArgs {
     Consts c;
@@ -981,12 +1200,15 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     const int Sact = (na + XRW - 1) / XRW;
     if (g.S < Sact) { if (threadIdx.x == 0) xfail(A.sy, XERR_PLACEMENT, x); return; }
     if (cW >= Sact) return;
-    const bool rec = VAL && x == 0;                     // this group writes the record
+    // every group carries the same D_t: group 0 writes D_t, the virtual rows' mass and the aggregate, group 1 (where there is one)
+    // the per-source record {w, ig D_{t-1}} — whose row 0 needs every member's virtual row, i.e. member 0 waits for everybody
+    // (spreading the three outputs of group 0 further — one each to groups 0, 2, 3 — was slower: 2.73 against 2.63 ms at N = 32)
+    const bool recD = VAL && x == 0, recL = VAL && x == 1 % A.groups;
     for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     for (int k = threadIdx.x; k < P * ne; k += blockDim.x) closh[k] = R.clo[k];
     for (int k = threadIdx.x; k < P; k += blockDim.x) {
         int w = A.src[(size_t)k * Sact + cW];
-        if (A.all_members || (rec && ((w >> 17) & 1))) w = (w & ~0xffff) | ((Sact - 1) << 8);
+        if (A.all_members || (recL && ((w >> 17) & 1))) w = (w & ~0xffff) | ((Sact - 1) << 8);
         srcsh[k] = w;
     }
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave index in a scalar register: column bases become scalar)
@@ -1131,7 +1353,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         for (int k = 0; k < DD; k++) pagg[k] = 0.0;
         double v0 = 0.0;                                // the record's row 0: the mass on every member's virtual row of this column
         if (!syncw) {
-            const bool need0 = rec && r0 == 0 && vnz && clo == 0;      // (wave-uniform)
+            const bool need0 = recL && r0 == 0 && vnz && clo == 0;      // (wave-uniform)
             if constexpr (VAL) {
                 if (need0 && lane < Sact) v0 = rows.load_one(hb + gx + ((size_t)e * Sact + lane) * 64 + 63, IV);
             }
@@ -1217,16 +1439,15 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
             }
             const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
             if constexpr (VAL) {
-                if (rec) {
-                    if (own) {
-                        R.Dseq[(size_t)(t + 1) * G + pt] = mx[IV];
-                        // what the tangent sweeps read per SOURCE: {w, ig * D_{t-1}} (k_lottery's w and ig)
-                        double Dfull = mxp[IV];
-                        if (r == 0 && clo == 0) Dfull += v0;
-                        R.lwg[base + r] = make_double2(lwr, igr * Dfull);
-                    } else if (virt) {
-                        A.Dvirt[((size_t)t * ne + e) * 64 + cW] = mx[IV];
-                    }
+                if (recL && own) {
+                    // what the tangent sweeps read per SOURCE: {w, ig * D_{t-1}} (k_lottery's w and ig)
+                    double Dfull = mxp[IV];
+                    if (r == 0 && clo == 0) Dfull += v0;
+                    R.lwg[base + r] = make_double2(lwr, igr * Dfull);
+                }
+                if (recD) {
+                    if (own) R.Dseq[(size_t)(t + 1) * G + pt] = mx[IV];
+                    else if (virt) A.Dvirt[((size_t)t * ne + e) * 64 + cW] = mx[IV];
                     // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307); a virtual row carries row 0's policy
                     const double pD = xwave_reduce63(live ? polr * mx[IV] : 0.0);
                     if (lane == 63) A.aggpart[pb] = pD;
