@@ -146,27 +146,34 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     # batches do not depend on each other, gets out of the latency-bound per-period launches. Measured first: HIP maps
     # streams onto a few hardware queues in creation order, and with the contexts the solves below create the two
     # streams would share one (and serialise).
-    hb2 = hb.clone()
+    # (Both on the launch schedule: persistent sweeps own the chip one at a time and are ordered behind one another.)
     torch.cuda.synchronize()
-    hb.set_stream(None)            # both contexts on their own HIP streams for this measurement
+    prev = os.environ.get("HANK_SCHEDULE")
+    os.environ["HANK_SCHEDULE"] = "launch"
+    try:
+        hbs = (hb.clone(), hb.clone())
+    finally:
+        if prev is None:
+            os.environ.pop("HANK_SCHEDULE", None)
+        else:
+            os.environ["HANK_SCHEDULE"] = prev
     try:
         bufs = [(torch.randn(2 * P * N, dtype=torch.float64, device=dev), torch.empty(P, dtype=torch.float64, device=dev),
                  torch.empty(P * N, dtype=torch.float64, device=dev)) for _ in range(2)]
         def both():
-            for h_, (dx_, ag_, out_) in zip((hb, hb2), bufs):
+            for h_, (dx_, ag_, out_) in zip(hbs, bufs):
                 h_.primal_jvp_dev(d_x.data_ptr(), dx_.data_ptr(), N, ag_.data_ptr(), out_.data_ptr())
-        both(); hb.sync(); hb2.sync()
+        both(); hbs[0].sync(); hbs[1].sync()
         t0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
             both()
-        hb.sync(); hb2.sync()
+        hbs[0].sync(); hbs[1].sync()
         el = (time.perf_counter() - t0) / reps
-        extra["two_batches_in_flight"] = {"tangents": 2 * N, "JVPs_per_s": 2 * N / el, "ms_per_pair": 1e3 * el}
+        extra["two_batches_in_flight"] = {"tangents": 2 * N, "JVPs_per_s": 2 * N / el, "ms_per_pair": 1e3 * el, "schedule": "launch-per-period"}
     finally:
-        hb.sync()
-        hb2.close()
-        hb.set_stream(torch_stream)
+        for h_ in hbs:
+            h_.sync(); h_.close()
     # wider batch on the same context: N = 256 tangents in one dual-sweep pass
     Nw = 256
     d_dx = torch.randn(2 * P * Nw, dtype=torch.float64, device=dev)
@@ -539,10 +546,6 @@ def main(argv=None):
     fence()
     primal_before = hb.stats()["primal_sweeps"]
     t0 = time.perf_counter()
-    # the XCD-local persistent schedule always runs the Float64 sweeps and the tangent sweeps as separate launches
-    split_keys = args.split or hb.stats()["schedule"] == 1
-    sweeps = {k: 0.0 for k in (("primal_backward", "primal_forward", "tangent_backward", "tangent_forward") if split_keys
-                               else ("dual_backward", "dual_forward"))}
     for _ in range(args.steps):
         step()
     fence()
@@ -552,6 +555,10 @@ def main(argv=None):
     st_timed = hb.stats()
     assert st_timed["primal_sweeps"] - primal_before == args.steps and st_timed["primal_memo_hits"] == 0, st_timed
     tm = hb.last_timings()          # HIP events on the library's stream around each sweep (last step)
+    # which sweeps the timed call ran: the dual-sweep launches (dual_*), or persistent sweeps (the Float64 backward sweep — with the
+    # partials in it when the batch is one pass: k_xdual_back — then the tangent sweeps; the forward one carries D_t: k_xfwd<D,true>)
+    split_keys = tm["dual_backward"]["ms"] <= 0.0
+    sweeps = {k: 0.0 for k in tm if tm[k]["ms"] > 0.0 and (k.startswith("dual") != split_keys)}
     if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -574,13 +581,20 @@ def main(argv=None):
         # dominant kernel: the per-period tangent kernels (k_tan_back / k_tan_fwd). One launch moves
         # the policy partials of ONE period for N directions: G*8*N algorithmic bytes
         # (B_alg = 2*P*G*8*(1+N) per batch = G*8 bytes per (sweep, period, direction)).
-        if schedule == 1:
-            # XCD-local persistent sweeps: ONE launch carries a whole sweep (P periods). The kernels that move the
-            # algorithmic bytes are the tangent sweeps (the policy-partials sequence: written once by k_xtan_back, read
-            # once by k_xtan_fwd): P*G*8*N_pass per launch; a batch wider than 32 runs as ceil(N/32) passes. The Float64
-            # sweeps (k_xsweep_*<0>) move P*G*8 bytes each and are latency-bound: reported beside, not hidden.
+        persistent = split_keys and launches.get("tangent_forward", P) < P
+        if persistent and not args.split and acc.get("tangent_backward", 0.0) < 0.05:
+            # the persistent Dual pass: ONE launch per sweep, value and partials together in both (k_xdual_back writes the policy
+            # and the policy partials of every period, k_xfwd<D, true> reads them): P*G*8*(1+N) algorithmic bytes per launch
+            dom = max(("primal_backward", "tangent_forward"), key=lambda k: acc[k])
+            kname = {"primal_backward": "k_xdual_back", "tangent_forward": "k_xfwd"}[dom]
+            bytes_per_launch = P * G * 8 * (1 + N)
+        elif persistent:
+            # XCD-local persistent sweeps at a recorded primal: ONE launch carries a whole sweep (P periods). The kernels that
+            # move the algorithmic bytes are the tangent sweeps (the policy-partials sequence: written once by k_xtan_back, read
+            # once by k_xfwd): P*G*8*N_pass per launch; a batch wider than 32 runs as ceil(N/32) passes. The Float64
+            # sweeps move P*G*8 bytes each and are latency-bound: reported beside, not hidden.
             dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
-            kname = {"tangent_backward": "k_xtan_back", "tangent_forward": "k_xtan_fwd"}[dom]
+            kname = {"tangent_backward": "k_xtan_back", "tangent_forward": "k_xfwd"}[dom]
             bytes_per_launch = P * G * 8 * N / launches[dom]
         elif split_keys:
             dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
@@ -619,7 +633,7 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale, "traffic_detail": pmc,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_launch_s,
                          "model_ceiling": model_ceiling(G, N, n_e),
-                         "schedule": "xcd-persistent" if schedule == 1 else "launch-per-period",
+                         "schedule": "xcd-persistent" if persistent else "launch-per-period",
                          "note": "avg launch = HIP-event time of the sweep's kernels on the library's stream / launches"},
             "whole_batch": {"B_alg_bytes": b_alg_batch, "achieved_GBs": b_alg_batch / (1e-3 * ms_per_step) / 1e9,
                             "frac_of_hbm_peak": b_alg_batch / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS},

@@ -1068,6 +1068,7 @@ static int x_primal(hank_ctx *ctx, const double *xhh, hipMemcpyKind kind, double
 }
 // value and N partials; xhh == nullptr keeps the recorded primal (hank_jvp): the partials are linear recurrences at
 // that record, so a y-iteration pays the Float64 sweeps once (NewtonRaphson.jl:91) and each JVP (:95) only the tangent sweeps
+static bool x_dual_back_fits(const hank_ctx *ctx, int D);
 static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcpyKind kind, int N, double *d_agg_out, double *d_dagg_out) {
     int rc = x_setup(ctx);
     if (rc) return rc;
@@ -1076,9 +1077,7 @@ static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcp
     if (rc) return rc;
     const size_t P = ctx->c.P;
     // a Dual pass of one pass (N <= 8 groups x 4): value and partials together in BOTH sweeps (k_xdual_back, k_xfwd<D, true>)
-    const XWork &X = ctx->xw;
-    const bool fused_back = xhh && ctx->xdual_back && w->passes.size() == 1 && X.maxt == 768 && 64 * (ctx->c.n_e + 1) <= X.maxt &&
-                            x_lds_dual_back(ctx->c, w->passes[0].D) <= (size_t)X.lds_max;
+    const bool fused_back = xhh && w->passes.size() == 1 && x_dual_back_fits(ctx, w->passes[0].D);
     HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
     if (xhh) {
         HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, kind, ctx->stream));
@@ -1101,7 +1100,18 @@ static bool x_tan_fits(const hank_ctx *ctx, int N) {
     return std::max(x_lds_tan_back(ctx->c, D), x_lds_fwd(ctx->c, D + 1)) <= (size_t)X.lds_max;
 }
 static bool use_x_jvp(const hank_ctx *ctx, int N) { return (ctx->schedule == 1 || (ctx->schedule == 2 && N <= ctx->xjvp_max)) && x_tan_fits(ctx, N); }
-static bool use_x_fused(const hank_ctx *ctx, int N) { return ctx->schedule == 1 && x_tan_fits(ctx, N); }      // auto: the dual-sweep launches hide the primal chain
+// hank_primal_jvp on the persistent sweeps. Forced schedule: always. auto: a batch of ONE pass (N <= 8 groups x 4) runs value and
+// partials together in both sweeps (k_xdual_back, k_xfwd<D, true>: 4.8 ms against 5.13 for the dual-sweep launches at 2000x11,
+// T=300, N=32; 3.3 against 4.2 at N=1); wider batches would be two backward sweeps at the same record: the launches keep them
+static bool x_dual_back_fits(const hank_ctx *ctx, int D) {
+    const XWork &X = ctx->xw;
+    return ctx->xdual_back && X.maxt == 768 && 64 * (ctx->c.n_e + 1) <= X.maxt && x_lds_dual_back(ctx->c, D) <= (size_t)X.lds_max;
+}
+static bool use_x_fused(const hank_ctx *ctx, int N) {
+    if (ctx->schedule < 1 || !x_tan_fits(ctx, N)) return false;
+    if (ctx->schedule == 1) return true;
+    return N <= XG * ctx->xw.dmax && x_dual_back_fits(ctx, ctx->xw.dmax);
+}
 
 // a sweep could not form its groups (or timed out): this context continues on the per-period launches
 static int to_launch_schedule(hank_ctx *ctx) {
@@ -1128,7 +1138,16 @@ int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out) {
 int hank_check(hank_ctx *ctx) {
     ENTER(ctx);
     if (!ctx) return HANK_ERR_BAD_ARG;
-    return fetch_device_error(ctx);
+    const int rc = fetch_device_error(ctx);
+    // the asynchronous entries cannot re-run a call: the error is reported (once), and a context whose schedule was not forced
+    // continues on the per-period launches, so the caller's next call succeeds
+    if (rc == HANK_ERR_SWEEP && ctx->schedule >= 1 && x_fallback_allowed(ctx)) {
+        char keep[sizeof(ctx->errmsg)];
+        memcpy(keep, ctx->errmsg, sizeof(keep));
+        (void)to_launch_schedule(ctx);
+        memcpy(ctx->errmsg, keep, sizeof(keep));
+    }
+    return rc;
 }
 
 int hank_primal(hank_ctx *ctx, const double *xhh, double *agg_out) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/<tag>_*: kernel trace + stats, FETCH_SIZE and WRITE_SIZE in separate counter passes
 # (MI355X_MICROARCH.md, HBM section), two SQ passes of <= 8 counters each (the SQ block has 8 slots), for the default
-# schedule and — tag suffix "x" — for the XCD-local persistent sweeps forced on every entry point.
+# schedule and — tag suffix "l" — for the per-period launches forced on every entry point (HANK_SCHEDULE=launch).
 # Run on the GPU box: gpurun -- 'bash scripts/profile_round.sh r02a'
 set -o pipefail
 TAG=${1:-dev}; R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/prof_$TAG
@@ -38,6 +38,6 @@ PY
   done
 }
 run_set $TAG || exit 1
-HANK_SCHEDULE=xcd run_set ${TAG}x
-head -14 $O/${TAG}_kernel_stats.csv
-head -8 $O/${TAG}x_kernel_stats.csv
+HANK_SCHEDULE=launch run_set ${TAG}l
+head -10 $O/${TAG}_kernel_stats.csv
+head -6 $O/${TAG}l_kernel_stats.csv

@@ -96,6 +96,16 @@ def test_async_entries_report_the_sweep_error_at_check(hank, monkeypatch):
     with pytest.raises(hank.HankHIPError, match="persistent") as ei:
         hb.check()
     assert ei.value.code == hank.hip.HANK_ERR_SWEEP
+    # reported once; a context whose schedule was not forced continues on the per-period launches: the caller's next call succeeds
+    ref = _block(hank, m, monkeypatch, sched="launch")
+    ref.set_boundary(ss.value, ss.D)
+    agg0 = ref.primal(x[2:4])
+    hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
+    hb.check()
+    st = hb.stats()
+    assert st["schedule"] == 0 and st["fallbacks"] == 1
+    assert np.array_equal(d_agg.cpu().numpy(), agg0)
+    ref.close()
     hb.close()
 
 
