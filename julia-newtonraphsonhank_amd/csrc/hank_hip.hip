@@ -478,10 +478,10 @@ static size_t x_lds_tan_back(const Consts &c, int D) {
     const int SLt = D == 4 ? 6 : D;      // XTileT<D>::SL
     return sizeof(double) * ((size_t)SLt * c.n_e * 64 + c.P + 1 + 3 * (size_t)c.P + 1 + 3 * (size_t)c.P * D) + sizeof(int) * (size_t)c.P + 64;
 }
-// k_xdual_back<D>: tile of D + 1 slots, Pi, the grid, the household inputs and this group's input tangents of every period
+// k_xdual_back<D>: tile of D + 1 slots, the grid, the household inputs and this group's input tangents of every period
 static size_t x_lds_dual_back(const Consts &c, int D) {
     const int NSL = D + 1, SLt = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);
-    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + 1 + c.n_a + 1 + 4 * (size_t)c.P + 3 * (size_t)c.P * D) + 64;
+    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + c.n_a + 1 + 4 * (size_t)c.P + 3 * (size_t)c.P * D) + 64;
 }
 // k_xfwd with NSL live slots (the D partials + the value): tile, Pi, {source range, clamped prefix} and source members of every period
 static size_t x_lds_fwd(const Consts &c, int NSL) {

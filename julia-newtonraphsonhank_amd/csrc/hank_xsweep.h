@@ -366,27 +366,6 @@ __device__ __forceinline__ void xtile_mix(const double *tl, const double *P, int
     }
 }
 
-// the same arithmetic with the 16 steps unrolled (the ones beyond n_e predicated off), coefficients from LDS: every tile read of
-// the pass is in flight at once and no register holds a coefficient
-template <int SL, int NS>
-__device__ __forceinline__ void xtile_mix_flat(const double *tl, const double *P, int ps, int ne, double *out) {
-    const int ks = 64 * SL;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if (k < ne) {
-            double v[SL];
-            if (SL == 1) v[0] = tl[(size_t)k * ks];
-            else {
-#pragma unroll
-                for (int q = 0; q < (NS + 1) / 2; q++) { const double2 d = reinterpret_cast<const double2 *>(tl + (size_t)k * ks)[q]; v[2 * q] = d.x; v[2 * q + 1] = d.y; }
-            }
-            const double p = P[k * ps];
-#pragma unroll
-            for (int q = 0; q < NS; q++) out[q] = k == 0 ? p * v[q] : out[q] + p * v[q];
-        }
-    }
-}
-
 // the same with the column of Pi held in registers (16 unrolled steps, the ones beyond n_e predicated off): no LDS read for
 // the coefficient, and every tile read of the pass can be in flight at once
 template <int SL, int NS>
@@ -981,8 +960,7 @@ __global__ void __launch_bounds__(MAXT) k_xdual_back(XDualBackArgs B) {
     const Consts &c = A.c;
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     double *tile = xl;                                  // [ne][64][SL]: slots 0..D-1 the partials of V, slot D the value
-    double *Pish = tile + (size_t)SL * ne * 64;         // [ne*ne]
-    double *ash = Pish + ((ne * ne + 1) & ~1);          // [na]
+    double *ash = tile + (size_t)SL * ne * 64;          // [na]
     double *xsh = ash + ((na + 1) & ~1);                // [P][4]: r_t, w_t, tr_t, rho_t
     double *dxsh = xsh + 4 * (size_t)P;                 // [P][3][D]: this group's dr, dw, dtr
     int *ctl = reinterpret_cast<int *>(dxsh + (size_t)P * 3 * D);
@@ -1012,7 +990,6 @@ __global__ void __launch_bounds__(MAXT) k_xdual_back(XDualBackArgs B) {
     const int ng = B.groups;
     const bool rc0 = 0 % ng == x, rc1 = 1 % ng == x, rc2 = 2 % ng == x, rc3 = 3 % ng == x, rc4 = 4 % ng == x, rc5 = 5 % ng == x, rc6 = 6 % ng == x, rc7 = 7 % ng == x;
     const size_t pt = (size_t)e * na + (own ? a : 0);
-    for (int k = threadIdx.x; k < ne * ne; k += blockDim.x) Pish[k] = c.Pi[k];
     for (int k = threadIdx.x; k < na; k += blockDim.x) ash[k] = c.a[k];
     for (int k = threadIdx.x; k < P; k += blockDim.x) {
         xsh[4 * k] = A.xhh[c.n_hh * k]; xsh[4 * k + 1] = A.xhh[c.n_hh * k + 1]; xsh[4 * k + 2] = hh_tr(c, A.xhh, k); xsh[4 * k + 3] = A.rho[k];
@@ -1041,6 +1018,9 @@ __global__ void __launch_bounds__(MAXT) k_xdual_back(XDualBackArgs B) {
         xtile_store_n<SL, NSL>(myt, z);
     }
     __syncthreads();
+    double pr[16];                                      // Pi[e, k]: this wave's coefficients of the mixing, in registers (1.94 -> 1.87 ms at
+#pragma unroll                                          // N=32 against LDS reads; the kernel sits at 168 VGPRs = 3 waves per SIMD)
+    for (int k = 0; k < 16; k++) pr[k] = k < ne ? c.Pi[e + ne * k] : 0.0;
     int guess = -1;
     unsigned episode = 0;
     XSTAMP1(0, son, 10);
@@ -1112,7 +1092,7 @@ __global__ void __launch_bounds__(MAXT) k_xdual_back(XDualBackArgs B) {
             const int tx = P - 1 - i;
             if (own) {
                 double mx[NSL];
-                xtile_mix_flat<SL, NSL>(tile + (size_t)lane * SL, Pish + e, ne, ne, mx);
+                xtile_mix_reg<SL, NSL>(tile + (size_t)lane * SL, pr, ne, mx);
                 const double bE = mx[IV] * c.beta;
                 const double ex = -1.0 / c.gamma;
                 if (pow_domain_error(bE, ex)) set_err(A.err, ERR_DOMAIN, tx, e, a);

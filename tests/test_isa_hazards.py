@@ -30,7 +30,7 @@ def test_every_sc1_dwordx4_store_is_followed_by_its_nop(tmp_path):
         assert re.match(r"s_nop\s+[1-9]", code[i + 1]), f"no s_nop after `{code[i]}` (next: `{code[i + 1]}`)"
     # the persistent sweeps must not have picked up scratch (a register spill would sit on their critical path)
     txt = out.read_text()
-    for kern in ("k_xtan_back", "k_xfwd", "k_xprimal_back"):
+    for kern in ("k_xtan_back", "k_xfwd", "k_xprimal_back", "k_xdual_back"):
         blocks = re.findall(r"\.amdhsa_kernel (\S*" + kern + r"\S*)\n(.*?)\.end_amdhsa_kernel", txt, re.S)
         assert blocks, kern
         for name, body in blocks:
