@@ -644,7 +644,7 @@ static void x_launch_fwd(const XWork &X, int D, bool val, dim3 grd, dim3 blk, si
 static void x_ensure_rng(hank_ctx *ctx) {
     XWork &X = ctx->xw;
     if (X.rng_valid) return;
-    hipLaunchKernelGGL(k_xunits_fwd, dim3((unsigned)ctx->c.P, (unsigned)X.Sact), dim3(64), 0, ctx->stream, ctx->c, ctx->R, X.Sact, X.srcF, X.unitsF, X.unit_overflow);
+    hipLaunchKernelGGL(k_xunits_fwd, dim3((unsigned)ctx->c.P, (unsigned)X.Sact), dim3(256), 0, ctx->stream, ctx->c, ctx->R, X.Sact, X.srcF, X.unitsF, X.unit_overflow);
     X.rng_valid = true;
 }
 

@@ -1470,18 +1470,26 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
 __global__ void k_xunits_fwd(Consts c, Record R, int Sact, int *src, int2 *units, int *overflow) {
     __shared__ int2 su[16][XUCAP];
     __shared__ int scnt[16], slo, shi, sany0;
-    const int t = blockIdx.x, m = blockIdx.y, ne = c.n_e, na = c.n_a;
+    __shared__ int sst[16][XRW + 3];                    // start[r0-1 .. r0+nrows] of every column: the walk below is serial per column,
+    const int t = blockIdx.x, m = blockIdx.y, ne = c.n_e, na = c.n_a;      // and as dependent global loads it was 86 us per record
     const int r0 = m * XRW, nrows = min(XRW, na - r0);
+    __shared__ int sclo[16], sclop[16], soff[17];       // clamped prefixes of this period and of the one before, unit offsets per column
     if (threadIdx.x == 0) { slo = m; shi = m; sany0 = 0; }
+    if ((int)threadIdx.x < ne) {
+        sclo[threadIdx.x] = R.clo[(size_t)t * ne + threadIdx.x];
+        sclop[threadIdx.x] = t > 0 ? R.clo[(size_t)(t - 1) * ne + threadIdx.x] : 0;
+    }
+    for (int k = threadIdx.x; k < ne * (XRW + 3); k += blockDim.x) {
+        const int e = k / (XRW + 3), q = k - e * (XRW + 3);
+        sst[e][q] = min(max(R.start[((size_t)t * ne + e) * (na + 1) + min(max(r0 - 1 + q, 0), na)], 0), na);
+    }
     __syncthreads();
     bool vnz = false;
-    if (t > 0)
-        for (int e = 0; e < ne; e++) vnz = vnz || R.clo[(size_t)(t - 1) * ne + e] > 0;
+    for (int e = 0; e < ne; e++) vnz = vnz || sclop[e] > 0;
     if ((int)threadIdx.x < ne) {
         const int e = threadIdx.x;
-        const int *st = R.start + ((size_t)t * ne + e) * (na + 1);
-        const int clo = R.clo[(size_t)t * ne + e];
-        auto S = [&](int rr) { return min(max(st[min(max(rr, 0), na)], 0), na); };     // (a record that is not a lottery must not turn into a long walk or an out-of-range row)
+        const int clo = sclo[e];
+        auto S = [&](int rr) { return sst[e][min(max(rr - (r0 - 1), 0), XRW + 2)]; };     // (clamped at the fill: a record that is not a lottery must not turn into a long walk or an out-of-range row)
         int n = 0, ta = 0;
         while (ta < nrows && n < XUCAP) {
             const int ja = S(r0 + ta - 1 < 0 ? 0 : r0 + ta - 1);
@@ -1508,13 +1516,20 @@ __global__ void k_xunits_fwd(Consts c, Record R, int Sact, int *src, int2 *units
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int tot = 0, anyclo = 0, anyopen = 0;
+        int off = 0;
+        for (int e = 0; e < ne; e++) { soff[e] = off; off += scnt[e]; }
+        soff[ne] = off;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < min(soff[ne], XUCAP); k += blockDim.x) {      // units numbered column by column
+        int e = 0;
+        while (e + 1 < ne && soff[e + 1] <= k) e++;
+        units[((size_t)t * Sact + m) * XUCAP + k] = su[e][k - soff[e]];
+    }
+    if (threadIdx.x == 0) {
+        int tot = soff[ne], anyclo = 0, anyopen = 0;
         for (int e = 0; e < ne; e++) {
-            for (int k = 0; k < scnt[e]; k++) {
-                if (tot < XUCAP) units[((size_t)t * Sact + m) * XUCAP + tot] = su[e][k];
-                tot++;
-            }
-            if (R.clo[(size_t)t * ne + e] > 0) anyclo = 1; else anyopen = 1;
+            if (sclo[e] > 0) anyclo = 1; else anyopen = 1;
         }
         if (tot > XUCAP) { atomicExch(overflow, 1); tot = XUCAP; }
         int ml = min(slo, m), mh = max(shi, m);
