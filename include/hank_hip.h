@@ -117,13 +117,18 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out);
  * context's device (hank_create_on); they are not validated. */
 int hank_primal_dev(hank_ctx *ctx, const double *d_xhh, double *d_agg_out);
 int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_out);
-int hank_check(hank_ctx *ctx); /* sync + fetch the device error word of the last primal          */
+/* hank_check: sync + fetch the device error word of the last primal. A persistent sweep that could not run (HANK_ERR_SWEEP:
+ * its groups did not form, a wait ran into its deadline) is reported here for the asynchronous entries — which cannot re-run
+ * a call — ONCE: a context whose schedule was not forced (HANK_SCHEDULE) continues on the per-period launches, so the caller's
+ * next call succeeds (hank_stats out[4] counts it). */
+int hank_check(hank_ctx *ctx);
 
 /* hank_primal_jvp == JVP(fullFunction, x, y) exactly as the reference evaluates it: the Dual pass
  * recomputes the primal (NewtonRaphson.jl:95; GeneralStructures.jl:546-547), so value and N partials
- * travel together. One call = hank_primal + hank_jvp, but both recurrences advance in ONE chain of
- * T launches per direction (the tangent sweep runs one period behind the primal sweep inside the same
- * launches) instead of two. Leaves the context exactly as hank_primal followed by hank_jvp would.
+ * travel together. One call = hank_primal + hank_jvp, but both recurrences advance together: a batch of one pass
+ * (N <= 32) as TWO persistent launches that carry value and partials in every workgroup group (k_xdual_back, k_xfwd<D, true>),
+ * a wider batch as ONE chain of T launches per direction (the tangent sweep runs one period behind the primal sweep inside
+ * the same launches). Leaves the context exactly as hank_primal followed by hank_jvp would.
  * PRIMAL MEMO (host-pointer form only): y_Iteration calls JVP(fullFunction, x, y) about 21 times per Newton step at ONE x
  * (NewtonRaphson.jl:91-95). When `xhh` and the boundary are bit-identical to the ones whose linearisation is on record,
  * hank_primal_jvp runs the tangent sweeps alone (= hank_jvp) and returns the recorded value: results equal the un-memoised

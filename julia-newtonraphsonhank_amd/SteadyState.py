@@ -131,6 +131,9 @@ class SSAssembler:
 @host_algebra
 def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vfi_tol=None, vfi: str = "auto") -> SteadyState:
     """Newton–Raphson on the free endogenous variables with step halving (SteadyState.jl:184-233)."""
+    from .NewtonRaphson import warm_linear_solver
+    from .GeneralStructures import vars_of_type
+    warm_linear_solver(len(vars_of_type(model, "endogenous")) * (model.compspec.T - 1))      # (library start-up behind this solve)
     asm = SSAssembler(model, ss_spec, vfi_tol, vfi)
 
     def F(p):
