@@ -793,7 +793,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_bac
     HIPC(ctx, hipGetLastError());
     rc = x_serialize_end(ctx);
     if (rc) return rc;
-    ctx->stats[0] += 2 * np;
+    ctx->stats[0] += skip_back ? np : 2 * np;
     X.last_passes = 1 + np;
     ctx->launches[2] = ctx->launches[3] = np;
     ctx->ev_valid[2] = ctx->ev_valid[3] = true;

@@ -207,3 +207,35 @@ def test_schedules_agree(hank):
     close(res["xcd"][4], res["launch"][4], rel=1e-12)
     close(res["xcd"][0], res["launch"][0], rel=1e-12)
     close(res["xcd"][1], res["launch"][1], rel=1e-11)
+
+
+def test_default_schedule_runs_one_pass_dual_batches_on_the_persistent_dual_pass(hank):
+    """hank_primal_jvp in the default schedule: a batch of one pass (N <= 32) is TWO persistent launches that carry value and
+    partials together (k_xdual_back, k_xfwd<D, true>), a wider batch the dual-sweep launches; either way the numbers are the
+    launches' (policies and partials bit for bit, aggregates to the order of their sums)."""
+    m, ss, _ = ks_setup(500, 4, 300)
+    P = 299
+    x, _ = ks_paths(m, ss, "x1", 0.01)
+    rng = np.random.default_rng(11)
+    y32, y40 = rng.standard_normal((2, P, 32)), rng.standard_normal((2, P, 40))
+    ref = _forced(hank, m, "launch")
+    ref.set_boundary(ss.value, ss.D)
+    hb = hank.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    n0 = hb.stats()["sweep_launches"]
+    agg, dagg = hb.primal_jvp(x[2:4], y32)
+    tm = hb.last_timings()
+    assert hb.stats()["schedule"] == 2 and hb.stats()["sweep_launches"] - n0 == 2
+    assert tm["dual_backward"]["ms"] <= 0.0 and tm["primal_backward"]["launches"] == 1 and tm["tangent_forward"]["launches"] == 1
+    agg0, dagg0 = ref.primal_jvp(x[2:4], y32)
+    close(agg, agg0, rel=1e-12); close(dagg, dagg0, rel=1e-11)
+    assert np.array_equal(hb.policy_seq(), ref.policy_seq()) and np.array_equal(hb.dpolicy_seq(32), ref.dpolicy_seq(32))
+    hb.primal_jvp(x[2:4] * 1.01, y32)                                           # (another x on record: the next call is no memo hit)
+    agg2, dagg2 = hb.primal_jvp(x[2:4], y32)
+    assert np.array_equal(agg2, agg) and np.array_equal(dagg2, dagg)          # reproducible bit for bit
+    aggw, daggw = hb.primal_jvp(x[2:4] * 1.02, y40)
+    assert hb.last_timings()["dual_backward"]["launches"] > 1                   # the dual-sweep launches
+    agg1, dagg1 = ref.primal_jvp(x[2:4] * 1.02, y40)
+    assert np.array_equal(aggw, agg1) and np.array_equal(daggw, dagg1)
+    assert hb.stats()["fallbacks"] == 0
+    ref.close()

@@ -46,7 +46,7 @@ def test_forced_persistent_sweeps_match_the_oracle(hank, n_a, n_e, T, N, shock):
     hb.set_boundary(ss.value, ss.D)
     agg, dagg = hb.primal_jvp(x[2:4], y)
     st = hb.stats()
-    assert st["schedule"] == 1 and st["fallbacks"] == 0 and st["sweep_launches"] >= 3
+    assert st["schedule"] == 1 and st["fallbacks"] == 0 and st["sweep_launches"] >= 2      # (a one-pass Dual pass is two persistent launches)
     cols, pols = [], []
     for c0 in range(0, N, SUPPORTED_N[-1]):
         c1 = min(N, c0 + SUPPORTED_N[-1])
