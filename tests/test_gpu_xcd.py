@@ -143,3 +143,45 @@ def test_persistent_sweeps_are_race_free_at_full_size(hank):
     assert st == 0
     close(agg, oagg[:, 0]); close(first[:, [3, 30]], oagg[:, 1:])
     hb.close()
+
+
+def test_persistent_dual_pass_is_race_free_at_full_size(hank, monkeypatch):
+    """The default benched entry at its benched size (2000x11, T=300, N=32: k_xdual_back<4> + k_xfwd<4, true>, every group
+    repeating the Float64 step and sharing the record arrays out for writing): 20 repetitions reproduce value, partials, policy
+    and policy partials bit for bit, the record they leave serves a later hank_jvp, and everything equals the per-period launches
+    (policies and partials bit for bit, aggregates to the order of their sums) and, for two columns, the oracle."""
+    m, ss, orc = ks_setup(2000, 11, 300)
+    P = 299
+    x, Z = ks_paths(m, ss, "x1", 0.01)
+    y = np.random.default_rng(22).standard_normal((2, P, 32))
+    monkeypatch.setenv("HANK_PRIMAL_MEMO", "0")            # every call runs its Float64 sweep
+    wd, pd_ = m.heterogeneity["wealth"], m.heterogeneity["productivity"]
+    hb = hank.HouseholdBlock(wd.grid, pd_.grid, pd_.transition, m.params.β, m.params.γ, m.params.borrow_cons, m.compspec.T,
+                             m.value_fn.value_fn_id)       # a context of its own, default schedule
+    monkeypatch.delenv("HANK_PRIMAL_MEMO", raising=False)
+    hb.set_boundary(ss.value, ss.D)
+    agg, dagg = hb.primal_jvp(x[2:4], y)
+    assert hb.last_timings()["dual_backward"]["ms"] <= 0.0 and hb.stats()["schedule"] == 2      # the persistent Dual pass ran
+    pol, dpol = hb.policy_seq(), hb.dpolicy_seq(32)
+    for k in range(20):
+        if k % 5 == 4:
+            hb.primal_jvp(x[2:4] * 1.01, y)                 # another record in between
+        a2, d2 = hb.primal_jvp(x[2:4], y)
+        assert np.array_equal(a2, agg) and np.array_equal(d2, dagg)
+    assert np.array_equal(hb.policy_seq(), pol) and np.array_equal(hb.dpolicy_seq(32), dpol)
+    later = hb.jvp(y[:, :, 5:6])                            # the record serves the persistent tangent sweeps
+    close(later[:, 0], dagg[:, 5], rel=1e-11)
+    ref = forced_block(hank, m, "launch")
+    ref.set_boundary(ss.value, ss.D)
+    a0, d0 = ref.primal_jvp(x[2:4], y)
+    assert np.array_equal(ref.policy_seq(), pol) and np.array_equal(ref.dpolicy_seq(32), dpol)
+    close(agg, a0, rel=1e-12); close(dagg, d0, rel=1e-11)
+    ref.close()
+    xr = np.zeros((P, 3)); xw = np.zeros((P, 3))
+    xr[:, 0], xw[:, 0] = x[2], x[3]
+    xr[:, 1:], xw[:, 1:] = y[0][:, [0, 31]], y[1][:, [0, 31]]
+    st, oagg, _ = orc.household_block(xr, xw, ss.value, ss.D, 2)
+    assert st == 0
+    close(agg, oagg[:, 0]); close(dagg[:, [0, 31]], oagg[:, 1:])
+    assert hb.stats()["fallbacks"] == 0 and hb.stats()["primal_memo_hits"] == 0
+    hb.close()
