@@ -31,6 +31,11 @@ while time.perf_counter() - t0 < secs:
     for N, y in ys.items():
         d = hb.jvp(y)
         assert np.array_equal(ref.setdefault(N, d), d), N
+    # the Dual pass (persistent for one-pass batches, the launches beyond) at an x that is never the one on record
+    k = n % 2
+    for q, N in enumerate((1, 16, 32, 64)):
+        a2, d2 = hb.primal_jvp(x[2:4] * (1.0 + 1e-3 * (k + 1) + 1e-4 * q), ys[N])      # (a different x per call: no memo hit)
+        assert np.array_equal(ref.setdefault(("dual_agg", k, N), a2), a2) and np.array_equal(ref.setdefault(("dual", k, N), d2), d2), (k, N)
     if n % 10 == 0:
         v, pol, it, nrm = hb.vfi(np.ones((2000, 11)), [ss.vars["r"], ss.vars["w"]], 1e-11)
         assert np.array_equal(ref.setdefault("v", v), v) and it == ref.setdefault("it", it)
