@@ -1486,33 +1486,56 @@ __global__ void k_xunits_fwd(Consts c, Record R, int Sact, int *src, int2 *units
     __syncthreads();
     bool vnz = false;
     for (int e = 0; e < ne; e++) vnz = vnz || sclop[e] > 0;
-    if ((int)threadIdx.x < ne) {
-        const int e = threadIdx.x;
+    // One wave per column (the block's waves take the columns in turn). The greedy walk "extend the unit while it has <= 64 lanes"
+    // is 63 dependent steps as a loop; the end of the unit that STARTS at target row ta is a monotone search, so lane ta finds it
+    // by bisection (nxt), all 63 at once, and lane 0 then follows the chain nxt[0], nxt[nxt[0]], ... — a handful of hops.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int e = wave; e < ne; e += nwaves) {
         const int clo = sclo[e];
         auto S = [&](int rr) { return sst[e][min(max(rr - (r0 - 1), 0), XRW + 2)]; };     // (clamped at the fill: a record that is not a lottery must not turn into a long walk or an out-of-range row)
-        int n = 0, ta = 0;
-        while (ta < nrows && n < XUCAP) {
-            const int ja = S(r0 + ta - 1 < 0 ? 0 : r0 + ta - 1);
+        // lanes of a unit that starts at `a` and ends before target row `b`: its sources, and every member's virtual row when it walks source 0
+        auto lanes_of = [&](int a, int b, int *ja_out, bool *has0_out) {
+            const int ja = S(r0 + a - 1 < 0 ? 0 : r0 + a - 1);
             const bool has0 = ja == 0 && clo <= 0 && vnz;        // (then source row 0 is the unit's first lane, if it has any)
-            int tb = ta + 1;
-            int cnt = max(S(r0 + tb) - ja, 0);
-            const int nv0 = (has0 && cnt > 0) ? Sact : 0;
-            while (tb < nrows) {
-                const int c2 = max(S(r0 + tb + 1) - ja, 0);
-                if (c2 + ((has0 && c2 > 0) ? Sact : 0) > 64) break;
-                tb++; cnt = c2;
+            const int cnt = max(S(r0 + b) - ja, 0);
+            *ja_out = ja; *has0_out = has0;
+            return cnt;
+        };
+        int nxt = nrows;
+        if (lane < nrows) {
+            int ja; bool has0;
+            (void)lanes_of(lane, lane + 1, &ja, &has0);
+            auto fits = [&](int b) { const int c2 = max(S(r0 + b) - ja, 0); return c2 + ((has0 && c2 > 0) ? Sact : 0) <= 64; };
+            int lo = lane + 1, hi = nrows;               // the unit ends at the largest b in [lane + 1, nrows] with every step up to it fitting
+            if (lo < hi && fits(lo + 1)) {               // (the count is monotone in b: a bisection)
+                if (fits(hi)) lo = hi;
+                else {
+                    lo = lo + 1;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (fits(mid)) lo = mid; else hi = mid; }
+                }
             }
+            nxt = lo;
+        }
+        int n = 0, ta = 0;
+        while (ta < nrows && n < XUCAP) {               // (wave-uniform: every lane follows the same chain)
+            const int tb = __shfl(nxt, ta, 64);
+            int ja; bool has0;
+            const int cnt = lanes_of(ta, tb, &ja, &has0);
             const int nv = (has0 && cnt > 0) ? Sact : 0;
-            (void)nv0;
             if (cnt > 0) {
-                su[e][n++] = make_int2(e | (ja << 4) | (cnt << 16), ta | (tb << 8) | (nv << 16));
-                atomicMin(&slo, ja / XRW); atomicMax(&shi, (ja + cnt - 1) / XRW);
-                if (nv) sany0 = 1;
+                if (lane == 0) {
+                    su[e][n] = make_int2(e | (ja << 4) | (cnt << 16), ta | (tb << 8) | (nv << 16));
+                    atomicMin(&slo, ja / XRW); atomicMax(&shi, (ja + cnt - 1) / XRW);
+                    if (nv) sany0 = 1;
+                }
+                n++;
             }
             ta = tb;
         }
-        if (ta < nrows) atomicExch(overflow, 1);
-        scnt[e] = n;
+        if (lane == 0) {
+            if (ta < nrows) atomicExch(overflow, 1);
+            scnt[e] = n;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
