@@ -224,6 +224,15 @@ int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]);
  * hank_primal_jvp[_dev]). */
 int hank_stats(hank_ctx *ctx, int64_t out[8]);
 
+/* Which implementation served the last tangent sweep and how the context chooses (bench.py and the tests name the kernel family
+ * they measured; the reference has one implementation, ForwardDiff's Dual pass, GeneralStructures.jl:542-550): out[0] the family of
+ * the last tangent sweep (0 = one launch per period, 1 = XCD-local persistent sweeps, 2 = on-chip wide sweeps: one workgroup per
+ * direction, the loop-carried state in registers), out[1] the wide sweeps' mode (0 off, 1 auto: batches of at least out[2]
+ * directions, 2 every batch: HANK_SCHEDULE=wide), out[2] that threshold (HANK_WIDE_MIN at hank_create), out[3] 1 when the grid fits
+ * the wide sweeps, out[4] the widest batch the persistent tangent sweeps take at a recorded primal, out[5] 1 when the tangent sweeps
+ * rebuild kc and v instead of reading them (record diet), out[6] bytes of the linearisation record, out[7] reserved. */
+int hank_info(hank_ctx *ctx, int64_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

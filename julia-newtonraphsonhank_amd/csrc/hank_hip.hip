@@ -6,6 +6,7 @@
 #include "hank_kernels.h"
 #include "hank_xsweep.h"
 #include "hank_jacobian.h"
+#include "hank_wide.h"
 #include "../../include/hank_hip.h"
 
 #include <cstdarg>
@@ -91,6 +92,15 @@ struct XWork {
     int last_passes = 0;            // sync blocks the last call used (their status words are checked)
 };
 
+// ---- on-chip wide sweeps (hank_wide.h): tangent buffers per batch width ----
+struct WTan {
+    int N = 0;
+    double *dxhh = nullptr;         // (n_hh, P, N) the caller's input tangents (staging for the host-pointer entries)
+    double *dpol = nullptr;         // [P][N][G]
+    double *dagg_cm = nullptr;      // (P, N) column-major
+    bool valid = false;             // dpol holds the partials of the current primal
+};
+
 struct hank_ctx {
     int device = 0;
     Consts c{};
@@ -124,6 +134,14 @@ struct hank_ctx {
     XWork xw;
     struct { double *dpT = nullptr, *iota = nullptr, *E = nullptr, *Cp = nullptr, *F = nullptr, *Dv = nullptr; int N = 0; } fn;   // hank_fake_news workspace
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
+    // on-chip wide sweeps: 0 = never, 1 = auto (batches of at least wide_min directions), 2 = every batch (HANK_SCHEDULE=wide: tests)
+    int wide_mode = 0, wide_min = 96;
+    size_t lds_max = 65536;
+    char *rec_slab = nullptr;      // the record's ONE allocation
+    size_t rec_bytes = 0;
+    std::list<WTan> wtans;         // most recently used first
+    WTan *wcur = nullptr;
+    std::vector<double> h_Pi, h_z;  // host copies (the wide sweeps take the mixing matrix as a kernel argument)
     long long stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // see hank_stats
     // primal memo of the host-pointer hank_primal_jvp (NewtonRaphson.jl:91-95 calls JVP(fullFunction, x, y) ~21 times at one x):
     // the x whose linearisation is on record, as the host handed it in
@@ -138,6 +156,11 @@ struct hank_ctx {
 };
 
 static int fail(hank_ctx *ctx, int code, const char *fmt, ...);
+static void w_invalidate(hank_ctx *ctx) { for (WTan &t : ctx->wtans) t.valid = false; }
+static void w_free_tan(WTan &w) {
+    (void)hipFree(w.dxhh); (void)hipFree(w.dpol); (void)hipFree(w.dagg_cm);
+    w = WTan();
+}
 static hipError_t join_side(hank_ctx *ctx) {
     if (!ctx->side_pending) return hipSuccess;
     ctx->side_pending = false;
@@ -728,6 +751,7 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullp
     ctx->primal_done = true;
     X.src_valid = false;
     for (XTan &t : X.tans) t.valid = false;
+    w_invalidate(ctx);
     ctx->xcur = nullptr;
     return HANK_OK;
 }
@@ -802,7 +826,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_bac
     w->valid = true;
     ctx->xcur = w;
     ctx->last_tan = 1;
-    for (TanWork &t : ctx->tws) t.valid = false;
+    for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     return HANK_OK;
 }
 
@@ -832,6 +856,140 @@ static int x_status(hank_ctx *ctx) {
                         h[k].status[1], h[k].ticket[0][0], h[k].ticket[1][0], h[k].ticket[2][0], h[k].ticket[3][0], h[k].ticket[4][0],
                         h[k].ticket[5][0], h[k].ticket[6][0], h[k].ticket[7][0]);
         }
+    return HANK_OK;
+}
+
+// ================================ on-chip wide sweeps (hank_wide.h): host side ====================
+// value-function families share the kernels (n_hh and the record diet are run-time / template switches); the number of
+// productivity states is a template parameter (the state of a grid row is a register array)
+#define HANK_WIDE_NE_LIST(X) X(2) X(3) X(4) X(5) X(7) X(11)
+static bool w_ne_instantiated(int ne) {
+#define X(NEV) if (ne == NEV) return true;
+    HANK_WIDE_NE_LIST(X)
+#undef X
+    return false;
+}
+static int w_threads(const Consts &c) { return std::max(64, ((c.n_a + WIDE_R - 1) / WIDE_R + 63) / 64 * 64); }
+static bool w_supported(const hank_ctx *ctx) {
+    const Consts &c = ctx->c;
+    return w_ne_instantiated(c.n_e) && w_threads(c) <= WIDE_MAXT && std::max(wide_lds_back(c), wide_lds_fwd(c)) <= ctx->lds_max &&
+           ctx->rec_bytes < 0x7fffffffull && (size_t)c.G * sizeof(double) < 0x7fffffffull;
+}
+static bool use_wide(const hank_ctx *ctx, int N) { return ctx->wide_mode == 2 || (ctx->wide_mode == 1 && N >= ctx->wide_min); }
+
+template <int NE>
+static int w_launch_ne(hank_ctx *ctx, bool fwd, int N, const WideArgs &a) {
+    const Consts &c = ctx->c;
+    WMat<NE> M;
+    for (int k = 0; k < NE; k++)
+        for (int e = 0; e < NE; e++) M.m[k * NE + e] = fwd ? ctx->h_Pi[k + NE * e] : ctx->h_Pi[e + NE * k];
+    for (int e = 0; e < NE; e++) M.z[e] = ctx->h_z[e];
+    const dim3 grd((unsigned)N), blk((unsigned)w_threads(c));
+    if (fwd) {
+        const size_t lds = wide_lds_fwd(c);
+        HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_fwd<NE, WIDE_R, WIDE_MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_wide_fwd<NE, WIDE_R, WIDE_MAXT>), grd, blk, lds, ctx->stream, a, M);
+    } else {
+        const size_t lds = wide_lds_back(c);
+        if (c.diet) {
+            HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_back<NE, WIDE_R, WIDE_MAXT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_wide_back<NE, WIDE_R, WIDE_MAXT, true>), grd, blk, lds, ctx->stream, a, M);
+        } else {
+            HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_back<NE, WIDE_R, WIDE_MAXT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_wide_back<NE, WIDE_R, WIDE_MAXT, false>), grd, blk, lds, ctx->stream, a, M);
+        }
+    }
+    return HANK_OK;
+}
+static int w_launch(hank_ctx *ctx, bool fwd, int N, const WideArgs &a) {
+#define X(NEV) if (ctx->c.n_e == NEV) return w_launch_ne<NEV>(ctx, fwd, N, a);
+    HANK_WIDE_NE_LIST(X)
+#undef X
+    return fail(ctx, HANK_ERR_BAD_ARG, "on-chip wide sweeps: n_e=%d is not instantiated", ctx->c.n_e);
+}
+
+static int w_ensure_tan(hank_ctx *ctx, int N, bool staging, WTan **out) {
+    for (auto it = ctx->wtans.begin(); it != ctx->wtans.end(); ++it)
+        if (it->N == N) {
+            ctx->wtans.splice(ctx->wtans.begin(), ctx->wtans, it);
+            WTan &w = ctx->wtans.front();
+            if (staging && !w.dxhh) HIPC(ctx, dmalloc(&w.dxhh, (size_t)ctx->c.n_hh * ctx->c.P * N));
+            *out = &w;
+            return HANK_OK;
+        }
+    const char *ce = getenv("HANK_TAN_CACHE");
+    const size_t keep = ce ? (size_t)atoi(ce) : 3;
+    while (ctx->wtans.size() >= (keep ? keep : 1)) {       // evict the least recently used — after the stream has drained
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->wcur == &ctx->wtans.back()) ctx->wcur = nullptr;
+        w_free_tan(ctx->wtans.back());
+        ctx->wtans.pop_back();
+    }
+    ctx->wtans.emplace_front();
+    WTan &w = ctx->wtans.front();
+    const Consts &c = ctx->c;
+    const size_t P = c.P, G = c.G;
+    w.N = N;
+    ctx->stats[1]++;
+    auto alloc = [&]() -> int {
+        if (staging) HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
+        HIPC(ctx, dmalloc(&w.dpol, P * (size_t)N * G));
+        HIPC(ctx, dmalloc(&w.dagg_cm, P * (size_t)N));
+        return HANK_OK;
+    };
+    const int rc = alloc();
+    if (rc) { w_free_tan(w); ctx->wtans.pop_front(); (void)hipGetLastError(); return rc; }
+    *out = &w;
+    return HANK_OK;
+}
+
+// the N partials at the recorded primal (either schedule may have recorded it): two launches, one workgroup per direction
+static int w_run_tangent(hank_ctx *ctx, WTan *w, const double *d_dxhh) {
+    const Consts &c = ctx->c;
+    hipStream_t s = ctx->stream;
+    int rc = x_serialize_begin(ctx);        // (a persistent sweep of another context must not find the chip half full of these workgroups)
+    if (rc) return rc;
+    WideArgs a{};
+    a.c = c; a.R = ctx->R; a.xhh = ctx->d_xhh; a.dxhh = d_dxhh; a.Ntot = w->N; a.n0 = 0; a.dpol = w->dpol; a.dagg = w->dagg_cm;
+    a.rec = ctx->rec_slab;
+    auto off = [&](const void *p) { return (unsigned)((const char *)p - ctx->rec_slab); };
+    const Record &R = ctx->R;
+    a.o_s = off(R.s); a.o_kc = off(R.kc); a.o_A = off(R.A); a.o_B = off(R.B); a.o_u = off(R.u); a.o_v = off(R.v); a.o_ib = off(R.ib);
+    a.o_lwg = off(R.lwg); a.o_seg = off(R.seg); a.o_D = off(R.Dseq); a.o_pol = off(R.pol);
+    HIPC(ctx, hipEventRecord(ctx->ev[3], s));
+    rc = w_launch(ctx, false, w->N, a);
+    if (rc) return rc;
+    HIPC(ctx, hipEventRecord(ctx->ev[4], s));
+    HIPC(ctx, join_side(ctx));              // the forward sweep reads D_t and the {w, ig D} record of the primal's forward sweep
+    HIPC(ctx, hipEventRecord(ctx->ev[7], s));
+    rc = w_launch(ctx, true, w->N, a);
+    if (rc) return rc;
+    HIPC(ctx, hipEventRecord(ctx->ev[5], s));
+    HIPC(ctx, hipGetLastError());
+    rc = x_serialize_end(ctx);
+    if (rc) return rc;
+    ctx->launches[2] = ctx->launches[3] = 1;
+    ctx->ev_valid[2] = ctx->ev_valid[3] = true;
+    ctx->ev_valid[4] = ctx->ev_valid[5] = false;
+    for (TanWork &t : ctx->tws) t.valid = false;
+    for (XTan &t : ctx->xw.tans) t.valid = false;
+    w_invalidate(ctx);
+    w->valid = true;
+    ctx->wcur = w;
+    ctx->last_tan = 2;
+    ctx->stats[0] += 2;
+    return HANK_OK;
+}
+static int w_jvp(hank_ctx *ctx, const double *dxhh, hipMemcpyKind kind, int N, double *d_dagg_out) {
+    WTan *w = nullptr;
+    const bool staging = kind != hipMemcpyDeviceToDevice;
+    int rc = w_ensure_tan(ctx, N, staging, &w);
+    if (rc) return rc;
+    const size_t P = ctx->c.P;
+    if (staging) HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
+    rc = w_run_tangent(ctx, w, staging ? w->dxhh : dxhh);
+    if (rc) return rc;
+    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, w->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
     return HANK_OK;
 }
 
@@ -901,16 +1059,26 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     HIPC(ctx, hipMemcpy(ctx->d_z, m->z_grid, sizeof(double) * c.n_e, hipMemcpyHostToDevice));
     HIPC(ctx, hipMemcpy(ctx->d_Pi, m->Pi, sizeof(double) * c.n_e * c.n_e, hipMemcpyHostToDevice));
     c.a = ctx->d_a; c.z = ctx->d_z; c.Pi = ctx->d_Pi;
+    ctx->h_Pi.assign(m->Pi, m->Pi + (size_t)c.n_e * c.n_e);
+    ctx->h_z.assign(m->z_grid, m->z_grid + c.n_e);
+    ctx->lds_max = prop.sharedMemPerBlock;
     Record &R = ctx->R;
-    HIPC(ctx, dmalloc(&R.s, P * G)); HIPC(ctx, dmalloc(&R.kc, P * G));
-    HIPC(ctx, dmalloc(&R.A, P * G)); HIPC(ctx, dmalloc(&R.B, P * G));
-    HIPC(ctx, dmalloc(&R.u, P * G)); HIPC(ctx, dmalloc(&R.v, P * G));
-    HIPC(ctx, dmalloc(&R.pol, P * G)); HIPC(ctx, dmalloc(&R.lw, P * G));
-    HIPC(ctx, dmalloc(&R.ig, P * G)); HIPC(ctx, dmalloc(&R.Dseq, (P + 1) * G));
-    HIPC(ctx, dmalloc(&R.ib, P * G)); HIPC(ctx, dmalloc(&R.lo, P * G));
-    HIPC(ctx, dmalloc(&R.start, P * (size_t)c.n_e * (c.n_a + 1)));
-    HIPC(ctx, dmalloc(&R.clo, P * (size_t)c.n_e));
-    HIPC(ctx, dmalloc(&R.lwg, P * G)); HIPC(ctx, dmalloc(&R.seg, P * G));
+    {   // the record is ONE allocation: the on-chip wide sweeps reach every array through one buffer descriptor (hank_wide.h)
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t d8 = P * G * sizeof(double);
+        const size_t o_s = carve(d8), o_kc = carve(d8), o_A = carve(d8), o_B = carve(d8), o_u = carve(d8), o_v = carve(d8), o_pol = carve(d8),
+                     o_lw = carve(d8), o_ig = carve(d8), o_D = carve((P + 1) * G * sizeof(double)), o_ib = carve(P * G * sizeof(int)),
+                     o_lo = carve(P * G * sizeof(int)), o_st = carve(P * (size_t)c.n_e * (c.n_a + 1) * sizeof(int)),
+                     o_clo = carve(P * (size_t)c.n_e * sizeof(int)), o_lwg = carve(P * G * sizeof(double2)), o_seg = carve(P * G * sizeof(int4));
+        HIPC(ctx, hipMalloc((void **)&ctx->rec_slab, off));
+        ctx->rec_bytes = off;
+        char *b = ctx->rec_slab;
+        R.s = (double *)(b + o_s); R.kc = (double *)(b + o_kc); R.A = (double *)(b + o_A); R.B = (double *)(b + o_B);
+        R.u = (double *)(b + o_u); R.v = (double *)(b + o_v); R.pol = (double *)(b + o_pol); R.lw = (double *)(b + o_lw);
+        R.ig = (double *)(b + o_ig); R.Dseq = (double *)(b + o_D); R.ib = (int *)(b + o_ib); R.lo = (int *)(b + o_lo);
+        R.start = (int *)(b + o_st); R.clo = (int *)(b + o_clo); R.lwg = (double2 *)(b + o_lwg); R.seg = (int4 *)(b + o_seg);
+    }
     HIPC(ctx, dmalloc(&ctx->d_ss_value, G));
     ctx->d_ss_D = R.Dseq;
     ctx->nbp = (c.n_a + RBP - 1) / RBP;
@@ -934,6 +1102,16 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
         ctx->schedule = 1;
         ctx->forced_xcd = true;
     }
+    // on-chip wide sweeps (hank_wide.h): "auto" sends tangent batches of at least wide_min directions to them (measured crossover,
+    // DESIGN.md section 4); a forced schedule (launch | xcd) keeps its one implementation; HANK_SCHEDULE=wide sends every batch (tests)
+    ctx->wide_mode = (w_supported(ctx) && !(se && (strcmp(se, "launch") == 0 || strcmp(se, "xcd") == 0))) ? 1 : 0;
+    if (se && strcmp(se, "wide") == 0) {
+        if (!w_supported(ctx))
+            return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=wide: %dx%d, T=%d does not fit the on-chip wide sweeps (n_e instantiated: 2,3,4,5,7,11; n_a <= %d; %zu bytes of LDS per workgroup, the device has %zu)",
+                        c.n_a, c.n_e, ctx->T, WIDE_R * WIDE_MAXT, std::max(wide_lds_back(c), wide_lds_fwd(c)), ctx->lds_max);
+        ctx->wide_mode = 2;
+    }
+    if (const char *wm = getenv("HANK_WIDE_MIN")) ctx->wide_min = std::max(1, atoi(wm));
     if (const char *xm = getenv("HANK_XJVP_MAX")) ctx->xjvp_max = atoi(xm);
     if (const char *pm = getenv("HANK_PRIMAL_MEMO")) ctx->memo_on = atoi(pm) != 0;
     if (const char *xd = getenv("HANK_XDUAL_BACK")) ctx->xdual_back = atoi(xd) != 0;
@@ -961,9 +1139,10 @@ int hank_destroy(hank_ctx *ctx) {
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->g_pback) (void)hipGraphExecDestroy(ctx->g_pback);
     if (ctx->g_pfwd) (void)hipGraphExecDestroy(ctx->g_pfwd);
-    Record &R = ctx->R;
-    (void)hipFree(R.s); (void)hipFree(R.kc); (void)hipFree(R.A); (void)hipFree(R.B); (void)hipFree(R.u); (void)hipFree(R.v);
-    (void)hipFree(R.pol); (void)hipFree(R.lw); (void)hipFree(R.ig); (void)hipFree(R.Dseq); (void)hipFree(R.ib); (void)hipFree(R.lo); (void)hipFree(R.start); (void)hipFree(R.clo); (void)hipFree(R.lwg); (void)hipFree(R.seg);
+    for (WTan &t : ctx->wtans) w_free_tan(t);
+    ctx->wtans.clear();
+    ctx->wcur = nullptr;
+    (void)hipFree(ctx->rec_slab);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
     (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 16; k++)
@@ -1015,7 +1194,7 @@ int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *s
     ctx->stationary = false;
     ctx->h_ss_value.assign(ss_end_value, ss_end_value + G);
     ctx->h_ss_D.assign(ss_init_D, ss_init_D + G);
-    for (TanWork &t : ctx->tws) t.valid = false;
+    for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     ctx->errmsg[0] = 0;
     return HANK_OK;
 }
@@ -1052,7 +1231,7 @@ static int run_primal(hank_ctx *ctx, double *d_agg_out) {
     ctx->ev_valid[4] = ctx->ev_valid[5] = false;
     ctx->primal_done = true;
     ctx->xw.src_valid = false; ctx->xw.rng_valid = false;
-    for (TanWork &t : ctx->tws) t.valid = false;
+    for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     return HANK_OK;
 }
 
@@ -1199,7 +1378,7 @@ static int run_jvp(hank_ctx *ctx) {
     HIPC(ctx, hipGraphLaunch(w.g_fwd, ctx->stream));
     HIPC(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     ctx->ev_valid[2] = ctx->ev_valid[3] = true;
-    for (TanWork &t : ctx->tws) t.valid = false;
+    for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     w.valid = true;
     ctx->last_tan = 0;
     for (XTan &t : ctx->xw.tans) t.valid = false;
@@ -1210,6 +1389,7 @@ int hank_jvp_dev(hank_ctx *ctx, const double *d_dxhh, int32_t N, double *d_dagg_
     ENTER(ctx);
     if (!ctx || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
+    if (use_wide(ctx, N)) return w_jvp(ctx, d_dxhh, hipMemcpyDeviceToDevice, N, d_dagg_out);
     if (use_x_jvp(ctx, N)) return x_dual(ctx, nullptr, d_dxhh, hipMemcpyDeviceToDevice, N, nullptr, d_dagg_out);
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
@@ -1227,6 +1407,16 @@ int hank_jvp(hank_ctx *ctx, const double *dxhh, int32_t N, double *dagg_out) {
     if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "hank_primal must be called before hank_jvp");
     const size_t P = ctx->c.P;
     int rc = HANK_OK;
+    if (use_wide(ctx, N)) {      // a wide batch at the recorded primal: the on-chip sweeps (no cross-workgroup waits: nothing to fall back from)
+        rc = w_jvp(ctx, dxhh, hipMemcpyHostToDevice, N, nullptr);
+        if (rc) return rc;
+        rc = fetch_device_error(ctx);
+        if (rc) return rc;
+        HIPC(ctx, hipMemcpyAsync(dagg_out, ctx->wcur->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->errmsg[0] = 0;
+        return HANK_OK;
+    }
     if (use_x_jvp(ctx, N)) {
         rc = x_dual(ctx, nullptr, dxhh, hipMemcpyHostToDevice, N, nullptr, nullptr);
         if (rc) return rc;
@@ -1273,7 +1463,7 @@ static int run_fused(hank_ctx *ctx) {
     ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
     ctx->primal_done = true;
     ctx->xw.src_valid = false; ctx->xw.rng_valid = false;
-    for (TanWork &t : ctx->tws) t.valid = false;
+    for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     w.valid = true;
     ctx->last_tan = 0;
     for (XTan &t : ctx->xw.tans) t.valid = false;
@@ -1285,6 +1475,10 @@ int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh
     ENTER(ctx);
     if (!ctx || !d_xhh || !d_dxhh || N < 1) return fail(ctx, HANK_ERR_BAD_ARG, "bad argument (N=%d)", N);
     if (!ctx->boundary_set) return fail(ctx, HANK_ERR_NOT_READY, "hank_set_boundary must be called first");
+    if (use_wide(ctx, N)) {           // a wide batch: the Float64 sweeps of the context's schedule, then the on-chip tangent sweeps
+        const int rc = hank_primal_dev(ctx, d_xhh, d_agg_out);
+        return rc ? rc : hank_jvp_dev(ctx, d_dxhh, N, d_dagg_out);
+    }
     note_primal_x(ctx, nullptr);      // (this entry never skips work: bench.py times it)
     ctx->stats[7]++;
     if (use_x_fused(ctx, N)) return x_dual(ctx, d_xhh, d_dxhh, hipMemcpyDeviceToDevice, N, d_agg_out, d_dagg_out);
@@ -1323,6 +1517,10 @@ int hank_primal_jvp(hank_ctx *ctx, const double *xhh, const double *dxhh, int32_
             HIPC(ctx, hipStreamSynchronize(ctx->stream));
         }
         return HANK_OK;
+    }
+    if (use_wide(ctx, N)) {
+        rc = hank_primal(ctx, xhh, agg_out);
+        return rc ? rc : hank_jvp(ctx, dxhh, N, dagg_out);
     }
     note_primal_x(ctx, nullptr);
     const double *d_dagg = nullptr;
@@ -1406,7 +1604,7 @@ int hank_fake_news(hank_ctx *ctx, double *F_out, double *Dv_out) {
     HIPC(ctx, join_side(ctx));      // D_1 and the {w, ig D} records come from the primal's forward sweep
     hipLaunchKernelGGL(k_fn_seed, dim3((unsigned)((N * P * N + 255) / 256)), dim3(256), 0, s, w.dxhh, N, P);
     HIPC(ctx, hipGraphLaunch(w.g_back, s));
-    for (TanWork &t : ctx->tws) t.valid = false;      // (w.dpol no longer belongs to a caller's batch)
+    for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);      // (w.dpol no longer belongs to a caller's batch)
     for (XTan &t : ctx->xw.tans) t.valid = false;
     // 2. the lottery impulse of every lag and input at once
     hipLaunchKernelGGL(k_fn_transpose, dim3((unsigned)((G + 31) / 32), (unsigned)((P + 31) / 32), (unsigned)N), dim3(256), 0, s, w.dpol, P, G, N, ctx->fn.dpT);
@@ -1456,6 +1654,13 @@ int hank_stats(hank_ctx *ctx, int64_t out[8]) {
     return HANK_OK;
 }
 
+int hank_info(hank_ctx *ctx, int64_t out[8]) {
+    if (!ctx || !out) return HANK_ERR_BAD_ARG;
+    out[0] = ctx->last_tan; out[1] = ctx->wide_mode; out[2] = ctx->wide_min; out[3] = w_supported(ctx) ? 1 : 0;
+    out[4] = ctx->xjvp_max; out[5] = ctx->c.diet; out[6] = (int64_t)ctx->rec_bytes; out[7] = 0;
+    return HANK_OK;
+}
+
 int hank_last_timings(hank_ctx *ctx, double out_ms[6], int32_t launches[6]) {
     if (!ctx || !out_ms) return HANK_ERR_BAD_ARG;
     ENTER(ctx);
@@ -1499,6 +1704,18 @@ int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
     ENTER(ctx);
     const size_t total = (size_t)ctx->c.P * ctx->c.G * N;
     double *tmp = nullptr;
+    if (ctx->last_tan == 2) {
+        WTan *w = ctx->wcur;
+        if (!w || !w->valid || w->N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
+        HIPC(ctx, dmalloc(&tmp, total));
+        hipLaunchKernelGGL(k_wide_export_dpol, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, w->dpol, ctx->c.G, ctx->c.P, N, tmp);
+        hipError_t e1 = hipMemcpyAsync(out, tmp, sizeof(double) * total, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+        HIPC(ctx, e1);
+        HIPC(ctx, e2);
+        return HANK_OK;
+    }
     if (ctx->last_tan == 1) {
         XTan *x = ctx->xcur;
         if (!x || !x->valid || x->N != N) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
     "hank_primal_jvp", "hank_primal_jvp_dev",
     "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
-    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings", "hank_stats", "hank_vfi", "hank_stationary_dist", "hank_fake_news", "hank_device_available",
+    "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings", "hank_stats", "hank_info", "hank_vfi", "hank_stationary_dist", "hank_fake_news", "hank_device_available",
 )
 
 
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
     lib.hank_forward_step_dual.argtypes = [vp, dp, dp, dp, dp, i32, dp, dp, dp, dp]
     lib.hank_last_timings.argtypes = [vp, dp, C.POINTER(i32)]
     lib.hank_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.hank_info.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.hank_vfi.argtypes = [vp, dp, C.c_double, i32, dp, dp, C.POINTER(i32), dp]
     lib.hank_stationary_dist.argtypes = [vp, dp, dp, C.c_double, i32, i32, C.POINTER(i32)]
     lib.hank_fake_news.argtypes = [vp, dp, dp]
@@ -269,6 +270,15 @@ class HouseholdBlock:
         names = ("sweep_launches", "tangent_workspaces_allocated", "graphs_captured", "schedule", "fallbacks", "vfi_iterations",
                  "primal_memo_hits", "primal_sweeps")
         return {k: int(out[i]) for i, k in enumerate(names)}
+
+    def info(self):
+        """which kernel family served the last tangent sweep and how the context chooses (include/hank_hip.h: hank_info)."""
+        out = (C.c_int64 * 8)()
+        self._chk(self._lib.hank_info(self._ctx, out))
+        names = ("last_tangent_family", "wide_mode", "wide_min", "wide_supported", "xjvp_max", "record_diet", "record_bytes", "reserved")
+        d = {k: int(out[i]) for i, k in enumerate(names)}
+        d["last_tangent_family_name"] = ("launch-per-period", "xcd-persistent", "on-chip-wide")[d["last_tangent_family"]]
+        return d
 
     def policy_seq(self) -> np.ndarray:
         """(n_a, n_e, P): policy matrix of every period (BackwardIteration's return value)."""
