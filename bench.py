@@ -189,20 +189,27 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     el = (time.perf_counter() - t0) / reps
     tm = hb.last_timings()
     G8 = hb.G * 8
-    if hb.stats()["schedule"] == 1:
+    fam = hb.info()["last_tangent_family_name"]
+    if fam == "on-chip-wide":
+        # one workgroup per direction, ONE launch per sweep (csrc/hank_wide.h): a launch moves the policy partials of every period
+        # and direction once, P*G*8*N bytes; the Float64 sweeps (hank_primal, XCD-local persistent) run before them and are timed
+        # in ms_per_step
+        kb, kf, np_, per, kpre = "tangent_backward", "tangent_forward", 1, P * Nw, "k_wide_"
+    elif hb.stats()["schedule"] == 1:
         kb, kf, np_ = "tangent_backward", "tangent_forward", tm["tangent_backward"]["launches"]
-        per = P * Nw
+        per, kpre = P * Nw, "k_xtan_"
     else:
         kb, kf, np_ = "dual_backward", "dual_forward", 1
-        per = tm["dual_backward"]["launches"] * (1 + Nw)
+        per, kpre = tm["dual_backward"]["launches"] * (1 + Nw), "k_fused_"
     b_alg_w = 2 * P * G8 * (1 + Nw)
     slow = kb if tm[kb]["ms"] >= tm[kf]["ms"] else kf
     ach_w = G8 * per / (1e-3 * tm[slow]["ms"]) / 1e9
-    extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el, "passes": np_,
+    extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el, "passes": np_, "family": fam,
+                           "sweeps_ms": {k: round(v["ms"], 4) for k, v in tm.items() if v["ms"] > 0},
                            "backward_sweep_GBs": G8 * per / (1e-3 * tm[kb]["ms"]) / 1e9,
                            "forward_sweep_GBs": G8 * per / (1e-3 * tm[kf]["ms"]) / 1e9,
                            # the same object as the headline's, for the slower sweep of the wide batch (HIP events on the library's stream)
-                           "roofline": {"bound": "hbm", "kernel": ("k_xtan_" if hb.stats()["schedule"] == 1 else "k_fused_") + ("back" if slow == kb else "fwd"),
+                           "roofline": {"bound": "hbm", "kernel": kpre + ("back" if slow == kb else "fwd"),
                                         "achieved": ach_w, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_w / HBM_PEAK_GBS, "traffic": None,
                                         "sweep_ms": tm[slow]["ms"], "launches": tm[slow]["launches"], "model_ceiling": model_ceiling(hb.G, Nw, hb.n_e)},
                            "whole_batch": {"B_alg_bytes": b_alg_w, "achieved_GBs": b_alg_w / el / 1e9, "frac_of_hbm_peak": b_alg_w / el / 1e9 / HBM_PEAK_GBS}}

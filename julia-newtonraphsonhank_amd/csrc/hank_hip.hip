@@ -135,7 +135,7 @@ struct hank_ctx {
     struct { double *dpT = nullptr, *iota = nullptr, *E = nullptr, *Cp = nullptr, *F = nullptr, *Dv = nullptr; int N = 0; } fn;   // hank_fake_news workspace
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     // on-chip wide sweeps: 0 = never, 1 = auto (batches of at least wide_min directions), 2 = every batch (HANK_SCHEDULE=wide: tests)
-    int wide_mode = 0, wide_min = 96;
+    int wide_mode = 0, wide_min = 184, num_cus = 256;
     size_t lds_max = 65536;
     char *rec_slab = nullptr;      // the record's ONE allocation
     size_t rec_bytes = 0;
@@ -875,7 +875,15 @@ static bool w_supported(const hank_ctx *ctx) {
     return w_ne_instantiated(c.n_e) && w_threads(c) <= WIDE_MAXT && std::max(wide_lds_back(c), wide_lds_fwd(c)) <= ctx->lds_max &&
            ctx->rec_bytes < 0x7fffffffull && (size_t)c.G * sizeof(double) < 0x7fffffffull;
 }
-static bool use_wide(const hank_ctx *ctx, int N) { return ctx->wide_mode == 2 || (ctx->wide_mode == 1 && N >= ctx->wide_min); }
+// auto: a workgroup (= a direction) per CU and round; a round costs what ~184 directions cost the per-period launches (measured at
+// 2000x11, T=300: 15.1 ms per round at a recorded primal against 0.082 ms per direction), so the batch goes to the wide sweeps when
+// its last round is at least that full (N = 256, 512: yes; N = 128, 300: no). wide_min (HANK_WIDE_MIN) is that fill, in directions.
+static bool use_wide(const hank_ctx *ctx, int N) {
+    if (ctx->wide_mode == 2) return true;
+    if (ctx->wide_mode != 1) return false;
+    const int rounds = (N + ctx->num_cus - 1) / ctx->num_cus;
+    return (long long)N * 256 >= (long long)rounds * ctx->wide_min * ctx->num_cus;      // (wide_min is quoted for a 256-CU chip)
+}
 
 template <int NE>
 static int w_launch_ne(hank_ctx *ctx, bool fwd, int N, const WideArgs &a) {
@@ -933,7 +941,7 @@ static int w_ensure_tan(hank_ctx *ctx, int N, bool staging, WTan **out) {
     ctx->stats[1]++;
     auto alloc = [&]() -> int {
         if (staging) HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
-        HIPC(ctx, dmalloc(&w.dpol, P * (size_t)N * G));
+        HIPC(ctx, dmalloc(&w.dpol, P * (size_t)N * G + 2));       // (+ 2: the last 16-byte load of an odd-sized grid reads 8 bytes past its row)
         HIPC(ctx, dmalloc(&w.dagg_cm, P * (size_t)N));
         return HANK_OK;
     };
@@ -955,7 +963,7 @@ static int w_run_tangent(hank_ctx *ctx, WTan *w, const double *d_dxhh) {
     auto off = [&](const void *p) { return (unsigned)((const char *)p - ctx->rec_slab); };
     const Record &R = ctx->R;
     a.o_s = off(R.s); a.o_kc = off(R.kc); a.o_A = off(R.A); a.o_B = off(R.B); a.o_u = off(R.u); a.o_v = off(R.v); a.o_ib = off(R.ib);
-    a.o_lwg = off(R.lwg); a.o_seg = off(R.seg); a.o_D = off(R.Dseq); a.o_pol = off(R.pol);
+    a.o_lwg = off(R.lwg); a.o_start = off(R.start); a.o_D = off(R.Dseq); a.o_pol = off(R.pol);
     HIPC(ctx, hipEventRecord(ctx->ev[3], s));
     rc = w_launch(ctx, false, w->N, a);
     if (rc) return rc;
@@ -1062,6 +1070,7 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     ctx->h_Pi.assign(m->Pi, m->Pi + (size_t)c.n_e * c.n_e);
     ctx->h_z.assign(m->z_grid, m->z_grid + c.n_e);
     ctx->lds_max = prop.sharedMemPerBlock;
+    ctx->num_cus = std::max(1, prop.multiProcessorCount);
     Record &R = ctx->R;
     {   // the record is ONE allocation: the on-chip wide sweeps reach every array through one buffer descriptor (hank_wide.h)
         size_t off = 0;
@@ -1638,6 +1647,11 @@ int hank_fake_news(hank_ctx *ctx, double *F_out, double *Dv_out) {
 }
 
 #ifdef HANK_XSTAMP
+int hank_debug_wstamps(hank_ctx *ctx, unsigned long long *out) {
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    HIPC(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(hank::g_wstamps), sizeof(unsigned long long) * 2 * 4 * 64));
+    return HANK_OK;
+}
 // dev build: the stamps of the last sweeps (see hank_xsweep.h)
 int hank_debug_stamps(hank_ctx *ctx, unsigned long long *out) {
     HIPC(ctx, hipStreamSynchronize(ctx->stream));

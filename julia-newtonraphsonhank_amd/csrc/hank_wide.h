@@ -6,10 +6,12 @@
 // state: a launch per period reads and writes it through the fabric (132 / 192 MB per launch for 45 MB algorithmic at N = 256,
 // profiles/r04n256_*), the XCD-local sweeps exchange it through an L2 behind flags (a latency chain of ~6 us per period). Here
 // the state of a direction never leaves its CU:
-//   * a workgroup owns ONE direction and the WHOLE n_a x n_e grid. Thread i owns the wealth rows i, i + NT, i + 2 NT, ... (R of
-//     them) and ALL n_e columns of each: R * n_e doubles of loop-carried state — the first 7 columns in VGPRs, the rest (n_e = 11:
-//     4 of them) in thread-private LDS slots (the registers are needed for the record that is on its way; a private slot costs
-//     two LDS accesses per period).
+//   * a workgroup owns ONE direction and the WHOLE n_a x n_e grid. Thread i owns two PAIRS of adjacent wealth rows — 2i, 2i+1 and
+//     2(i + NT), 2(i + NT) + 1 — and ALL n_e columns of each: R * n_e = 44 doubles of loop-carried state at n_e = 11, the first 7
+//     columns in VGPRs, the rest in thread-private LDS slots (the registers are needed for the record that is on its way; a
+//     private slot costs two LDS accesses per period). Adjacent rows make every record, policy-partial and LDS-column access a
+//     16-byte one: the per-CU vector-memory path is what bounds this family (one CU streams the whole record of a period for ONE
+//     direction), and 8-byte accesses cost it twice the instructions per byte.
 //   * the n_e x n_e mixing (V' Pi' backward, D Pi forward) is lane-local: a row's n_e numbers are one lane's, the matrix
 //     streams through scalar registers from the kernel arguments. No LDS tile, no barrier.
 //   * what does cross lanes — the bracket gather ds[ib], ds[ib+1] backward, the lottery's two-target push forward — goes through a
@@ -48,40 +50,58 @@ __device__ __forceinline__ double wide_uniform(double v) {
 __device__ __forceinline__ void wide_pin(double &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ int wide_opaque_zero(int t, int q) { return __builtin_amdgcn_readfirstlane((t >> (27 + (q & 3))) & 1); }
 
-// y = M x for one grid row, in place: x's n_e numbers are this lane's registers, the n_e^2 coefficients stream through SCALAR
-// registers, a row of coefficients per input column, the next one on its way while this one is used (all 121 at once would need
-// 242 SGPRs — and the compiler, seeing the same loop-invariant loads in every row and period, hoists them all and spills: `zero`
-// is a zero it cannot see through, so each row's loads stay where they are used).
+// y = M x for R grid rows at once, in place: a row's n_e numbers are this lane's registers (columns >= KR: its private LDS slots),
+// the n_e^2 coefficients stream through SCALAR registers, one row of n_e coefficients per input column k, the next one on its
+// way while this one is used by all R rows (R * n_e fused multiply-adds per scalar round trip: with one grid row per trip the
+// scalar-cache latency, ~200 clocks, was exposed 44 times per period — 4.3 us of a 30 us period in the stamps). All n_e^2 at
+// once would need 242 SGPRs — and the compiler, seeing the same loop-invariant loads in every period, hoists them all and
+// spills: `zero` is a zero it cannot see through, the empty asm ties each row of loads to its place in the arithmetic.
 // Order of the sums: k ascending, first term unrounded-added (as xtile_mix_reg).
-template <int NE>
-__device__ __forceinline__ void wide_mix(double (&x)[NE], const double *m, int zero) {
+template <int NE, int R, int KR, int LSTRIDE>
+__device__ __forceinline__ void wide_mix(double (&x)[R][KR], double *lst, const double *m, int zero) {
 #pragma clang fp contract(fast)
-    double y[NE], cf[2][NE];
+    constexpr int KL = NE - KR;
+    double y[R][NE], cf[2][NE], xl[2][R];
     int off = zero;
 #pragma unroll
     for (int e = 0; e < NE; e++) cf[0][e] = m[off + e];
 #pragma unroll
     for (int k = 0; k < NE; k++) {
         if (k + 1 < NE) {
-            // (the empty asm ties the loads to this point of the row's arithmetic: as free-floating scalar loads the instruction
-            // selector lines all of a period's up at the top of the block, and they spill)
-            if (k == 0) asm volatile("" : "+s"(off) : "v"(x[0]));
-            else asm volatile("" : "+s"(off) : "v"(y[0]));
+            if (k == 0) asm volatile("" : "+s"(off) : "v"(x[0][0]));
+            else asm volatile("" : "+s"(off) : "v"(y[0][0]));
 #pragma unroll
             for (int e = 0; e < NE; e++) cf[(k + 1) & 1][e] = m[off + (k + 1) * NE + e];
-        }
-        const double xk = x[k];
+            if (k + 1 >= KR) {
 #pragma unroll
-        for (int e = 0; e < NE; e++) y[e] = k == 0 ? cf[0][e] * xk : y[e] + cf[k & 1][e] * xk;
+                for (int q = 0; q < R; q++) xl[(k + 1) & 1][q] = lst[((k + 1 - KR) * R + q) * LSTRIDE];
+            }
+        }
+        if (k == 0 && KR == 0) {
+#pragma unroll
+            for (int q = 0; q < R; q++) xl[0][q] = lst[q * LSTRIDE];
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const double xk = k < KR ? x[q][k < KR ? k : 0] : xl[k & 1][q];
+#pragma unroll
+            for (int e = 0; e < NE; e++) y[q][e] = k == 0 ? cf[0][e] * xk : y[q][e] + cf[k & 1][e] * xk;
+        }
     }
     // (the results are pinned HERE: each has one use, inside a column's code, and the compiler would sink the whole sum — and
     // every coefficient, as a spilled scalar — down to it)
 #pragma unroll
-    for (int e = 0; e < NE; e++) { x[e] = y[e]; asm volatile("" : "+v"(x[e])); }
+    for (int q = 0; q < R; q++) {
+#pragma unroll
+        for (int e = 0; e < KR; e++) { x[q][e] = y[q][e]; asm volatile("" : "+v"(x[q][e])); }
+#pragma unroll
+        for (int k = 0; k < KL; k++) lst[(k * R + q) * LSTRIDE] = y[q][KR + k];
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// buffer accesses: a scalar descriptor per array, a 32-bit lane offset (the row: shared by every array), a scalar offset (period and column)
+// buffer accesses: ONE scalar descriptor for the whole record, a 32-bit lane offset (the row pair: shared by every array), a scalar
+// offset (array, period and column)
 typedef unsigned int wv2u __attribute__((ext_vector_type(2)));
 typedef unsigned int wv4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wide_rsrc(const void *p) {
@@ -91,17 +111,34 @@ __device__ __forceinline__ double wide_ld64(__amdgpu_buffer_rsrc_t rs, int vo, i
     const wv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0);
     return __hiloint2double((int)q.y, (int)q.x);
 }
-__device__ __forceinline__ double wide_ld64_nt(__amdgpu_buffer_rsrc_t rs, int vo, int so) {
-    const wv2u q = __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 2);
-    return __hiloint2double((int)q.y, (int)q.x);
+__device__ __forceinline__ wv2u wide_ld2i(__amdgpu_buffer_rsrc_t rs, int vo, int so) { return __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0); }
+template <int AUX>
+__device__ __forceinline__ void wide_ld2d(__amdgpu_buffer_rsrc_t rs, int vo, int so, double &a, double &b) {    // two adjacent doubles: one 16-byte load
+    const wv4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, AUX);
+    a = __hiloint2double((int)q.y, (int)q.x); b = __hiloint2double((int)q.w, (int)q.z);
 }
-__device__ __forceinline__ int wide_ld32(__amdgpu_buffer_rsrc_t rs, int vo, int so) { return (int)__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0); }
 __device__ __forceinline__ wv4u wide_ld128(__amdgpu_buffer_rsrc_t rs, int vo, int so) { return __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0); }
+__device__ __forceinline__ void wide_st2d_nt(double a, double b, __amdgpu_buffer_rsrc_t rs, int vo, int so) {
+    wv4u q;
+    q.x = (unsigned)__double2loint(a); q.y = (unsigned)__double2hiint(a); q.z = (unsigned)__double2loint(b); q.w = (unsigned)__double2hiint(b);
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, vo, so, 2);
+}
 __device__ __forceinline__ void wide_st64_nt(double v, __amdgpu_buffer_rsrc_t rs, int vo, int so) {
     wv2u q;
     q.x = (unsigned)__double2loint(v); q.y = (unsigned)__double2hiint(v);
     __builtin_amdgcn_raw_buffer_store_b64(q, rs, vo, so, 2);
 }
+
+// dev build only (make stamp): s_memtime of wave 0 / lane 0 of workgroup 0 at fixed points of periods [100, 104)
+#ifdef HANK_XSTAMP
+__device__ unsigned long long g_wstamps[2][4][64];
+#define WSTAMP(sw, per, i)                                                                                          \
+    do {                                                                                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (per) >= 100 && (per) < 104) g_wstamps[sw][(per) - 100][i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define WSTAMP(sw, per, i) do {} while (0)
+#endif
 
 struct WideArgs {
     Consts c;
@@ -109,21 +146,39 @@ struct WideArgs {
     const double *xhh;      // [n_hh*P] household inputs of the recorded primal
     const double *dxhh;     // (n_hh, P, Ntot) column-major: the input tangents as the caller hands them in
     int Ntot, n0;           // workgroup b carries direction n0 + b
-    double *dpol;           // [P][Ntot][G] policy partials (written backward, read forward)
+    double *dpol;           // [P][Ntot][G] (+ 2 spare) policy partials (written backward, read forward)
     double *dagg;           // (P, Ntot) column-major (forward sweep)
     // the record is ONE allocation (hank_create): every array is reached through ONE buffer descriptor plus its byte offset from
     // `rec` (a descriptor is four scalar registers; eleven of them, next to the mixing's coefficient stream, spilled)
     const void *rec;
-    unsigned o_s, o_kc, o_A, o_B, o_u, o_v, o_ib, o_lwg, o_seg, o_D, o_pol;
+    unsigned o_s, o_kc, o_A, o_B, o_u, o_v, o_ib, o_lwg, o_start, o_D, o_pol;
 };
 
-// dynamic LDS of the two kernels
+// dynamic LDS of the two kernels: the exchanged column holds a slot for every row a thread may own (R * WIDE_MAXT >= n_a)
 static inline size_t wide_lds_back(const Consts &c) {
-    return sizeof(double) * (2 * (size_t)((c.n_a + 2) & ~1) + 8 * (size_t)c.P + (size_t)wide_kl(c.n_e) * WIDE_R * WIDE_MAXT);
+    return sizeof(double) * (2 * (size_t)WIDE_R * WIDE_MAXT + 8 * (size_t)c.P + (size_t)wide_kl(c.n_e) * WIDE_R * WIDE_MAXT);
 }
 static inline size_t wide_lds_fwd(const Consts &c) {
-    return sizeof(double) * (4 * ((size_t)c.n_a + 1) + 64 + (size_t)wide_kl(c.n_e) * WIDE_R * WIDE_MAXT) + sizeof(int) * ((size_t)c.P * c.n_e + 4);
+    return sizeof(double) * (4 * (size_t)WIDE_R * WIDE_MAXT + 64 + (size_t)wide_kl(c.n_e) * WIDE_R * WIDE_MAXT) + sizeof(int) * ((size_t)c.P * c.n_e + 4);
 }
+
+// this thread's rows: two pairs of adjacent rows, pair j = rows 2 (j NT + tid), + 1. A lane whose pair lies beyond the grid reads
+// row 0's record (finite numbers), keeps zeros in the forward sweep, and stores nothing.
+template <int R>
+struct WideRows {
+    int row[R], o8[R / 2], o4[R / 2], o16[R / 2];
+    bool ok[R];
+    __device__ __forceinline__ void init(int NT, int tid, int na) {
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) {
+            const int r0 = 2 * (j * NT + tid);
+            row[2 * j] = r0; row[2 * j + 1] = r0 + 1;
+            ok[2 * j] = r0 < na; ok[2 * j + 1] = r0 + 1 < na;
+            const int rc = ok[2 * j] ? r0 : 0;
+            o8[j] = rc * 8; o4[j] = rc * 4; o16[j] = rc * 16;
+        }
+    }
+};
 
 // ---- backward: dV_t from dV_{t+1}; sequence X(P-1) Y(P-1) | X(P-2) Y(P-2) | ... (k_xtan_back's expressions) ------------------
 //   X: dE = Pi dV_{t+1} (lane-local); ds = kc dE - rho ((z_e dw + dtr) + s dr)           KrusellSmith.jl:59-62 under Dual
@@ -131,14 +186,14 @@ static inline size_t wide_lds_fwd(const Consts &c) {
 template <int NE, int R, int MAXT, bool DIET>
 __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
 #pragma clang fp contract(fast)
-    constexpr int KL = wide_kl(NE), KR = NE - KL;
+    static_assert(R % 2 == 0, "rows come in adjacent pairs");
+    constexpr int KL = wide_kl(NE), KR = NE - KL, CS = R * MAXT;      // CS: slots of an exchanged column
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const int na = c.n_a, P = c.P, NT = blockDim.x, tid = threadIdx.x, G = c.G;
     const int n = A.n0 + blockIdx.x;
-    const int nap = (na + 2) & ~1;          // (slot n_a takes the writes of the lanes beyond the grid)
-    double *buf = xl;                       // [2][nap] the column being exchanged
-    double *uni = xl + 2 * (size_t)nap;     // [P][8]: rho_t, 1 + r_t, w_t, tr_t, dr_t, dw_t, dtr_t of this direction
+    double *buf = xl;                       // [2][CS] the column being exchanged
+    double *uni = xl + 2 * (size_t)CS;      // [P][8]: rho_t, 1 + r_t, w_t, tr_t, dr_t, dw_t, dtr_t of this direction
     double *lst = uni + 8 * (size_t)P + tid;        // [KL][R][MAXT]: this thread's slots of the LDS-resident columns of the state (compile-time strides: immediate offsets)
     for (int k = tid; k < P; k += NT) {
         const double r = A.xhh[c.n_hh * k];
@@ -146,17 +201,11 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
         uni[8 * k] = 1.0 / (1.0 + r); uni[8 * k + 1] = 1.0 + r; uni[8 * k + 2] = A.xhh[c.n_hh * k + 1]; uni[8 * k + 3] = hh_tr(c, A.xhh, k);
         uni[8 * k + 4] = dx[0]; uni[8 * k + 5] = dx[1]; uni[8 * k + 6] = c.n_hh > 2 ? dx[2] : 0.0; uni[8 * k + 7] = 0.0;
     }
-    int a[R], o8[R], o4[R];
-    bool ok[R];
+    WideRows<R> rw;
+    rw.init(NT, tid, na);
     double xa[R];
 #pragma unroll
-    for (int q = 0; q < R; q++) {
-        const int row = q * NT + tid;
-        ok[q] = row < na;
-        a[q] = ok[q] ? row : na;
-        o8[q] = (ok[q] ? row : 0) * 8; o4[q] = (ok[q] ? row : 0) * 4;     // (a lane beyond the grid reads row 0's record and stores nothing)
-        xa[q] = c.a[ok[q] ? row : 0];
-    }
+    for (int q = 0; q < R; q++) xa[q] = c.a[rw.ok[q] ? rw.row[q] : 0];
     double dV[R][KR];
 #pragma unroll
     for (int q = 0; q < R; q++) {
@@ -166,67 +215,70 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
         for (int k = 0; k < KL; k++) lst[(k * R + q) * MAXT] = 0.0;
     }
     const __amdgpu_buffer_rsrc_t rs = wide_rsrc(A.rec);
-    // The record of a column, SINGLE-buffered: every group of loads is issued the moment the registers it lands in have been
-    // used for the last time (two full stages in flight next to the state do not fit 256 VGPRs: the allocator spilled the
-    // freshly loaded values, waiting for each of them). What the loads then have to hide behind: the knots `s` of the next column
-    // the whole Y half and the barrier; ib, A, B the rest of the Y half, the next X half and the barrier; u, v a little more.
+    // The record of a column lives in ONE register stage; each group of its arrays is re-loaded for the NEXT column the moment the
+    // current column has used it for the last time (the knots after the X half, ib / A / B after the gather, u / v after dV): every
+    // load has a whole column's time to land, and the column's loads are issued at three places instead of one burst — the CU's
+    // vector-memory path (what bounds this family: ~30 B/clk per CU from L2) keeps working while the waves do arithmetic.
     struct Stage { double s[R], kc[DIET ? 1 : R], cA[R], cB[R], cu[R], cv[R]; int ib[R]; } S;
-    auto col_off = [&](int t, int e, int zt) { return t * G + e * na + zt; };   // (zt: an opaque zero of the period — the column offsets are not hoisted out of the period loop)
     auto load_X = [&](int so) {
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            S.s[q] = wide_ld64(rs, o8[q], A.o_s + so * 8);
-            if constexpr (!DIET) S.kc[q] = wide_ld64(rs, o8[q], A.o_kc + so * 8);
+        for (int j = 0; j < R / 2; j++) {
+            wide_ld2d<0>(rs, rw.o8[j], A.o_s + so * 8, S.s[2 * j], S.s[2 * j + 1]);
+            if constexpr (!DIET) wide_ld2d<0>(rs, rw.o8[j], A.o_kc + so * 8, S.kc[2 * j], S.kc[2 * j + 1]);
         }
     };
     auto load_Y1 = [&](int so) {
 #pragma unroll
-        for (int q = 0; q < R; q++) { S.ib[q] = wide_ld32(rs, o4[q], A.o_ib + so * 4); S.cA[q] = wide_ld64(rs, o8[q], A.o_A + so * 8); S.cB[q] = wide_ld64(rs, o8[q], A.o_B + so * 8); }
+        for (int j = 0; j < R / 2; j++) {
+            const wv2u iq = wide_ld2i(rs, rw.o4[j], A.o_ib + so * 4);
+            S.ib[2 * j] = (int)iq.x; S.ib[2 * j + 1] = (int)iq.y;
+            wide_ld2d<0>(rs, rw.o8[j], A.o_A + so * 8, S.cA[2 * j], S.cA[2 * j + 1]);
+            wide_ld2d<0>(rs, rw.o8[j], A.o_B + so * 8, S.cB[2 * j], S.cB[2 * j + 1]);
+        }
     };
     auto load_Y2 = [&](int so) {
 #pragma unroll
-        for (int q = 0; q < R; q++) { S.cu[q] = wide_ld64(rs, o8[q], A.o_u + so * 8); S.cv[q] = wide_ld64(rs, o8[q], A.o_v + so * 8); }
+        for (int j = 0; j < R / 2; j++) {
+            wide_ld2d<0>(rs, rw.o8[j], A.o_u + so * 8, S.cu[2 * j], S.cu[2 * j + 1]);
+            wide_ld2d<0>(rs, rw.o8[j], A.o_v + so * 8, S.cv[2 * j], S.cv[2 * j + 1]);
+        }
     };
     __syncthreads();
-    { const int so = col_off(P - 1, 0, 0); load_X(so); load_Y1(so); load_Y2(so); }
+    { const int so = (P - 1) * G; load_X(so); load_Y1(so); load_Y2(so); }
     int pb = 0;
     for (int t = P - 1; t >= 0; t--) {
+        WSTAMP(0, t, 0);
         // (uniform over the workgroup: scalar registers)
         const double rho = wide_uniform(uni[8 * t]), opr = wide_uniform(uni[8 * t + 1]), w = wide_uniform(uni[8 * t + 2]), tr = wide_uniform(uni[8 * t + 3]);
         const double dr = wide_uniform(uni[8 * t + 4]), dw = wide_uniform(uni[8 * t + 5]), dtr = wide_uniform(uni[8 * t + 6]);
-        // ---- the mixing, row by row: dE[e] = sum_k Pi[e, k] dV[k]
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-            double x[NE];
-#pragma unroll
-            for (int e = 0; e < KR; e++) x[e] = dV[q][e];
-#pragma unroll
-            for (int k = 0; k < KL; k++) x[KR + k] = lst[(k * R + q) * MAXT];
-            wide_mix<NE>(x, M.m, wide_opaque_zero(t, q));
-#pragma unroll
-            for (int e = 0; e < KR; e++) dV[q][e] = x[e];
-#pragma unroll
-            for (int k = 0; k < KL; k++) lst[(k * R + q) * MAXT] = x[KR + k];
-        }
-        const int zt = wide_opaque_zero(t, 0);
+        // ---- the mixing: dE[e] = sum_k Pi[e, k] dV[k], all of this thread's rows per coefficient row
+        wide_mix<NE, R, KR, MAXT>(dV, lst, M.m, wide_opaque_zero(t, 1));
+        const int zt = wide_opaque_zero(t, 0);      // (an opaque zero of the period: the column offsets are not hoisted out of the period loop)
         const __amdgpu_buffer_rsrc_t rs_dp = wide_rsrc(A.dpol + ((size_t)t * A.Ntot + n) * (size_t)G);
+        WSTAMP(0, t, 1);
         // ---- column by column: knot partials -> LDS column -> bracket gather -> policy partials, dV_t
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const int last = e + 1 == NE;
-            const int son = col_off(last ? (t > 0 ? t - 1 : 0) : t, last ? 0 : e + 1, zt);     // the next column (of the next period after the last)
+            const int son = (last ? (t > 0 ? t - 1 : 0) : t) * G + (last ? 0 : e + 1) * na + zt;      // the next column (of the next period behind the last)
             const double ze = M.z[e], wz = w * ze + tr, zd = ze * dw + dtr;
-            double *const col = buf + pb * nap;
+            double *const col = buf + pb * CS;
+            double ds[R];
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const double dE = e < KR ? dV[q][e < KR ? e : 0] : lst[((e - KR) * R + q) * MAXT];
                 double kc;
                 if constexpr (DIET) kc = diet_kc(c, S.s[q], rho, opr, wz, xa[q]); else kc = S.kc[q];
-                col[a[q]] = kc * dE - rho * (zd + S.s[q] * dr);
+                ds[q] = kc * dE - rho * (zd + S.s[q] * dr);
+                wide_pin(ds[q]);
             }
             __builtin_amdgcn_sched_barrier(0);      // (the loads must not be scheduled above the last use of the registers they refill)
             load_X(son);
+#pragma unroll
+            for (int j = 0; j < R / 2; j++) *reinterpret_cast<double2 *>(col + rw.row[2 * j]) = make_double2(ds[2 * j], ds[2 * j + 1]);
+            WSTAMP(0, t, 2 + 4 * e);
             xlds_barrier();
+            WSTAMP(0, t, 3 + 4 * e);
             double dg[R];
 #pragma unroll
             for (int q = 0; q < R; q++) {
@@ -234,20 +286,24 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
                 dg[q] = S.cA[q] * d0 + S.cB[q] * d1;
                 wide_pin(dg[q]);
             }
-            __builtin_amdgcn_sched_barrier(0);      // (the loads must not be scheduled above the last use of the registers they refill)
+            __builtin_amdgcn_sched_barrier(0);
             load_Y1(son);
+            WSTAMP(0, t, 5 + 4 * e);
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 double dVn = S.cu[q] * dr + S.cv[q] * ((xa[q] * dr + zd) - dg[q]);
                 wide_pin(dVn);
                 if (e < KR) dV[q][e < KR ? e : 0] = dVn; else lst[((e - KR) * R + q) * MAXT] = dVn;
             }
-            __builtin_amdgcn_sched_barrier(0);      // (the loads must not be scheduled above the last use of the registers they refill)
+            __builtin_amdgcn_sched_barrier(0);
             load_Y2(son);
             const int sd = (e * na + zt) * 8;
 #pragma unroll
-            for (int q = 0; q < R; q++)
-                if (ok[q]) wide_st64_nt(dg[q], rs_dp, o8[q], sd);
+            for (int j = 0; j < R / 2; j++) {
+                if (rw.ok[2 * j + 1]) wide_st2d_nt(dg[2 * j], dg[2 * j + 1], rs_dp, rw.o8[j], sd);
+                else if (rw.ok[2 * j]) wide_st64_nt(dg[2 * j], rs_dp, rw.o8[j], sd);
+            }
+            WSTAMP(0, t, 4 + 4 * e);
             pb ^= 1;
         }
     }
@@ -262,30 +318,25 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
 template <int NE, int R, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
 #pragma clang fp contract(fast)
-    constexpr int KL = wide_kl(NE), KR = NE - KL;
+    static_assert(R % 2 == 0, "rows come in adjacent pairs");
+    constexpr int KL = wide_kl(NE), KR = NE - KL, CS = R * MAXT;
+    constexpr int NWM = MAXT / 64;                          // wave slots of the per-wave sums (the slots of waves that do not exist stay zero)
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const Record &Rc = A.R;
     const int na = c.n_a, P = c.P, NT = blockDim.x, tid = threadIdx.x, G = c.G;
     const int n = A.n0 + blockIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    constexpr int NWM = MAXT / 64;                          // wave slots of the per-wave sums (the slots of waves that do not exist stay zero)
-    double2 *cb = reinterpret_cast<double2 *>(xl);          // [2][na + 1] {cL, cH} of the column being exchanged (slot n_a: the lanes beyond the grid)
-    double *red = xl + 4 * ((size_t)na + 1);                // [2][16] per-wave sums of the clamped prefix
+    double *cLa = xl;                                       // [2][CS] a source's push to its lower target ...
+    double *cHa = xl + 2 * (size_t)CS;                      // [2][CS] ... and to the upper one (two arrays: a gathered term is ONE 8-byte read)
+    double *red = xl + 4 * (size_t)CS;                      // [2][16] per-wave sums of the clamped prefix
     double *aggred = red + 32;                              // [2][16] per-wave parts of a period's aggregate
     double *lst = aggred + 32 + tid;                        // [KL][R][MAXT] this thread's slots of the LDS-resident columns
     int *closh = reinterpret_cast<int *>(aggred + 32 + (size_t)KL * R * MAXT);      // [P][NE]
     for (int k = tid; k < P * NE; k += NT) closh[k] = min(max(Rc.clo[k], 0), na);
     if (tid < 64) red[tid] = 0.0;                           // red and aggred
-    int a[R], o8[R], o16[R];
-    bool ok[R];
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-        const int row = q * NT + tid;
-        ok[q] = row < na;
-        a[q] = ok[q] ? row : na;
-        o8[q] = (ok[q] ? row : 0) * 8; o16[q] = (ok[q] ? row : 0) * 16;
-    }
+    WideRows<R> rw;
+    rw.init(NT, tid, na);
     double dD[R][KR];
 #pragma unroll
     for (int q = 0; q < R; q++) {
@@ -295,85 +346,96 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
         for (int k = 0; k < KL; k++) lst[(k * R + q) * MAXT] = 0.0;
     }
     const __amdgpu_buffer_rsrc_t rs = wide_rsrc(A.rec);
-    // the record of a column: the SOURCE half (lottery weights, policy partials, D_t, pol_{t-1}) single-buffered — reloaded for the
-    // next column the moment the push has been written to LDS; the TARGET half (the three segment bounds) double-buffered, it is
-    // small and needed right behind the barrier (see k_wide_back)
-    struct Src { double w[R], g[R], dp[R], Dn[R], pp[R]; } S;
-    struct Seg { int s0[R], s1[R], s2[R]; } sg[2];
+    // the record of a column in ONE register stage (see k_wide_back): the source half (lottery weights, policy partials, D_t,
+    // pol_{t-1}) is re-loaded for the next column once the push is written, the target half (the segment bounds: four consecutive
+    // entries of `start` serve a pair of rows) once the gather is done
+    struct Src { double w[R], g[R], dp[R], Dn[R], pp[R]; int s0[R], s1[R], s2[R]; } S;
+    int so4[R / 2];                                         // byte offset of start[r0 - 1] (start[0] for the first pair) within a column of `start`
+#pragma unroll
+    for (int j = 0; j < R / 2; j++) so4[j] = (rw.ok[2 * j] ? max(rw.row[2 * j] - 1, 0) : 0) * 4;
     auto load_src = [&](int t, int e, int zt) {
         const int pt = e * na + zt, so = t * G + pt;
         const __amdgpu_buffer_rsrc_t rs_dp = wide_rsrc(A.dpol + ((size_t)t * A.Ntot + n) * (size_t)G);
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            const wv4u wg = wide_ld128(rs, o16[q], A.o_lwg + so * 16);
-            S.w[q] = __hiloint2double((int)wg.y, (int)wg.x); S.g[q] = __hiloint2double((int)wg.w, (int)wg.z);
-            S.dp[q] = wide_ld64_nt(rs_dp, o8[q], pt * 8);
-            S.Dn[q] = wide_ld64(rs, o8[q], A.o_D + (so + G) * 8);                       // D_t (post-transition)
-            S.pp[q] = wide_ld64(rs, o8[q], A.o_pol + (t > 0 ? so - G : so) * 8);        // pol_{t-1}: its product with dD_{t-1} belongs to dagg_{t-1}
+        for (int j = 0; j < R / 2; j++) {
+            wide_ld2d<0>(rs, rw.o16[j], A.o_lwg + so * 16, S.w[2 * j], S.g[2 * j]);
+            wide_ld2d<0>(rs, rw.o16[j], A.o_lwg + so * 16 + 16, S.w[2 * j + 1], S.g[2 * j + 1]);
+            wide_ld2d<2>(rs_dp, rw.o8[j], pt * 8, S.dp[2 * j], S.dp[2 * j + 1]);
+            wide_ld2d<0>(rs, rw.o8[j], A.o_D + (so + G) * 8, S.Dn[2 * j], S.Dn[2 * j + 1]);                        // D_t (post-transition)
+            wide_ld2d<0>(rs, rw.o8[j], A.o_pol + (t > 0 ? so - G : so) * 8, S.pp[2 * j], S.pp[2 * j + 1]);         // pol_{t-1}: its product with dD_{t-1} belongs to dagg_{t-1}
         }
     };
-    auto load_seg = [&](Seg &T, int t, int e, int zt) {
-        const int so = t * G + e * na + zt;
+    auto load_seg = [&](int t, int e, int zt) {
+        const int so = ((t * NE + e) * (na + 1) + zt) * 4;
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            const wv4u v = wide_ld128(rs, o16[q], A.o_seg + so * 16);
-            T.s0[q] = (int)v.x; T.s1[q] = (int)v.y; T.s2[q] = (int)v.z;
+        for (int j = 0; j < R / 2; j++) {
+            const wv4u v = wide_ld128(rs, so4[j], A.o_start + so);
+            const bool first = rw.row[2 * j] == 0;          // the pair (0, 1): start[-1] does not exist, row 0's upper segment is empty (k_lottery's seg)
+            S.s0[2 * j] = (int)v.x; S.s1[2 * j] = first ? (int)v.x : (int)v.y; S.s2[2 * j] = first ? (int)v.y : (int)v.z;
+            S.s0[2 * j + 1] = first ? (int)v.x : (int)v.y; S.s1[2 * j + 1] = first ? (int)v.y : (int)v.z; S.s2[2 * j + 1] = first ? (int)v.z : (int)v.w;
         }
     };
     __syncthreads();
     load_src(0, 0, 0);
-    load_seg(sg[0], 0, 0, 0);
+    load_seg(0, 0, 0);
     int pb = 0;
     double aggBp = 0.0;                     // sum dpol_{t-1} D_{t-1} over this thread's points (waiting for its other half)
     double *const outn = A.dagg + (size_t)n * P;
     for (int t = 0; t < P; t++) {
+        WSTAMP(1, t, 0);
         double aggA = 0.0, aggB = 0.0;
         const int zt = wide_opaque_zero(t, 0);
 #pragma unroll
         for (int e = 0; e < NE; e++) {
-            const int b = e & 1, last = e + 1 == NE, nb = last ? 0 : ((e + 1) & 1);
+            const int last = e + 1 == NE;
             const int tn = last ? (t + 1 < P ? t + 1 : t) : t, en = last ? 0 : e + 1;
-            __builtin_amdgcn_sched_barrier(0);      // (the loads must not be scheduled above the last use of the registers they refill)
-            if (nb != b) load_seg(sg[nb], tn, en, zt);
-            const Seg &T = sg[b];
             const int clo = closh[t * NE + e];
-            double2 *const col = cb + pb * (na + 1);
-            double cs = 0.0;
+            double *const cL = cLa + pb * CS, *const cH = cHa + pb * CS;
+            double cs = 0.0, pl[R], ph[R];
 #pragma unroll
-            for (int q = 0; q < R; q++) {           // (branch-free: a lane beyond the grid carries zeros, reads row 0's record and writes slot n_a)
+            for (int q = 0; q < R; q++) {           // (branch-free: a lane beyond the grid carries zeros and reads row 0's record)
                 const double x = e < KR ? dD[q][e < KR ? e : 0] : lst[((e - KR) * R + q) * MAXT];
                 const double g = S.g[q] * S.dp[q];
-                col[a[q]] = make_double2((1.0 - S.w[q]) * x - g, S.w[q] * x + g);
+                pl[q] = (1.0 - S.w[q]) * x - g; ph[q] = S.w[q] * x + g;
                 aggA += S.pp[q] * x;                // (t = 0: x = 0)
-                aggB += ok[q] ? S.dp[q] * S.Dn[q] : 0.0;
-                cs += a[q] < clo ? x : 0.0;
+                aggB += rw.ok[q] ? S.dp[q] * S.Dn[q] : 0.0;
+                cs += (rw.ok[q] && rw.row[q] < clo) ? x : 0.0;
+                wide_pin(pl[q]); wide_pin(ph[q]);
             }
             wide_pin(aggA); wide_pin(aggB); wide_pin(cs);
             __builtin_amdgcn_sched_barrier(0);      // (the loads must not be scheduled above the last use of the registers they refill)
             load_src(tn, en, zt);
+#pragma unroll
+            for (int j = 0; j < R / 2; j++) {
+                *reinterpret_cast<double2 *>(cL + rw.row[2 * j]) = make_double2(pl[2 * j], pl[2 * j + 1]);
+                *reinterpret_cast<double2 *>(cH + rw.row[2 * j]) = make_double2(ph[2 * j], ph[2 * j + 1]);
+            }
             if (clo > 0) {                                      // (uniform) the mass point: sources clamped at the first grid point (:54-58)
                 cs = xwave_reduce63(cs);
                 if (lane == 63) red[pb * 16 + wv] = cs;
             }
+            WSTAMP(1, t, 2 + 4 * e);
             xlds_barrier();
+            WSTAMP(1, t, 3 + 4 * e);
             if (e == 0 && t >= 2 && tid == 0) {                 // the aggregate of period t-2, whose parts were written at the end of period t-1
                 double s = 0.0;
 #pragma unroll
                 for (int k = 0; k < NWM; k++) s += aggred[((t - 1) & 1) * 16 + k];
                 outn[t - 2] = s;
             }
+            // gather: target r sums its sources j in [s0, s2) in order — the upper parts (cH) of [s0, s1), then the lower parts (cL) of [s1, s2)
             double acc[R];
             int cnt = 0;
 #pragma unroll
-            for (int q = 0; q < R; q++) { acc[q] = 0.0; cnt = max(cnt, ok[q] ? T.s2[q] - T.s0[q] : 0); }
-            for (int k = 0; __any(k < cnt); k += 2) {           // (branch-free inside: a source beyond the segments reads the spare slot and adds zero)
+            for (int q = 0; q < R; q++) { acc[q] = 0.0; cnt = max(cnt, rw.ok[q] ? S.s2[q] - S.s0[q] : 0); }
+            for (int k = 0; __any(k < cnt); k += 2) {           // (branch-free inside: a term beyond the segments reads slot 0 and adds zero)
 #pragma unroll
                 for (int q = 0; q < R; q++) {
-                    const int j = T.s0[q] + k;
-                    const bool p0 = ok[q] && j < T.s2[q], p1 = ok[q] && j + 1 < T.s2[q];
-                    const double2 c0 = col[p0 ? j : na], c1 = col[p1 ? j + 1 : na];
-                    acc[q] += p0 ? (j < T.s1[q] ? c0.y : c0.x) : 0.0;
-                    acc[q] += p1 ? (j + 1 < T.s1[q] ? c1.y : c1.x) : 0.0;
+                    const int j = S.s0[q] + k;
+                    const bool p0 = rw.ok[q] && j < S.s2[q], p1 = rw.ok[q] && j + 1 < S.s2[q];
+                    const double v0 = (j < S.s1[q] ? cH : cL)[p0 ? j : 0], v1 = (j + 1 < S.s1[q] ? cH : cL)[p1 ? j + 1 : 0];
+                    acc[q] += p0 ? v0 : 0.0;
+                    acc[q] += p1 ? v1 : 0.0;
                 }
             }
             if (clo > 0 && tid == 0) {                          // thread 0 owns row 0 (q = 0)
@@ -387,24 +449,14 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
                 wide_pin(acc[q]);
                 if (e < KR) dD[q][e < KR ? e : 0] = acc[q]; else lst[((e - KR) * R + q) * MAXT] = acc[q];
             }
-            __builtin_amdgcn_sched_barrier(0);      // (the loads must not be scheduled above the last use of the registers they refill)
-            if (nb == b) load_seg(sg[nb], tn, en, zt);          // (odd n_e, last column: its own buffer is free only now)
+            __builtin_amdgcn_sched_barrier(0);
+            load_seg(tn, en, zt);
+            WSTAMP(1, t, 4 + 4 * e);
             pb ^= 1;
         }
-        // ---- exogenous transition, row by row: dD_t[e2] = sum_k dD_mid[k] Pi[k, e2] (ForwardIteration.jl:95-99)
-#pragma unroll
-        for (int q = 0; q < R; q++) {
-            double x[NE];
-#pragma unroll
-            for (int e = 0; e < KR; e++) x[e] = dD[q][e];
-#pragma unroll
-            for (int k = 0; k < KL; k++) x[KR + k] = lst[(k * R + q) * MAXT];
-            wide_mix<NE>(x, M.m, wide_opaque_zero(t, q));
-#pragma unroll
-            for (int e = 0; e < KR; e++) dD[q][e] = x[e];
-#pragma unroll
-            for (int k = 0; k < KL; k++) lst[(k * R + q) * MAXT] = x[KR + k];
-        }
+        WSTAMP(1, t, 1);
+        // ---- exogenous transition: dD_t[e2] = sum_k dD_mid[k] Pi[k, e2] (ForwardIteration.jl:95-99)
+        wide_mix<NE, R, KR, MAXT>(dD, lst, M.m, wide_opaque_zero(t, 1));
         if (t > 0) {                                            // dagg_{t-1} = sum pol_{t-1} dD_{t-1} + sum dpol_{t-1} D_{t-1}
             const double s = xwave_reduce63(aggA + aggBp);
             if (lane == 63) aggred[(t & 1) * 16 + wv] = s;
@@ -416,9 +468,12 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
 #pragma unroll
     for (int e = 0; e < NE; e++)
 #pragma unroll
-        for (int q = 0; q < R; q++) {
-            const double x = e < KR ? dD[q][e < KR ? e : 0] : lst[((e - KR) * R + q) * MAXT];
-            aggA += wide_ld64(rs, o8[q], A.o_pol + ((P - 1) * G + e * na) * 8) * x;      // (zeros beyond the grid)
+        for (int j = 0; j < R / 2; j++) {
+            double p0, p1;
+            wide_ld2d<0>(rs, rw.o8[j], A.o_pol + ((P - 1) * G + e * na) * 8, p0, p1);
+            const double x0 = e < KR ? dD[2 * j][e < KR ? e : 0] : lst[((e - KR) * R + 2 * j) * MAXT];
+            const double x1 = e < KR ? dD[2 * j + 1][e < KR ? e : 0] : lst[((e - KR) * R + 2 * j + 1) * MAXT];
+            aggA += p0 * x0 + p1 * x1;                          // (zeros beyond the grid)
         }
     const double s = xwave_reduce63(aggA + aggBp);
     if (lane == 63) aggred[(P & 1) * 16 + wv] = s;

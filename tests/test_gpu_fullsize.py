@@ -104,6 +104,7 @@ def test_wide_batch_N256_full_size(big):
     yw = np.random.default_rng(7).standard_normal((2, 299, N))
     yw[:, :, :32] = y                                  # the first 32 columns are the N=32 batch
     aggw, daggw = hb.primal_jvp(x[2:4], yw)
+    assert hb.info()["last_tangent_family_name"] == "on-chip-wide"      # a full round: one workgroup per direction (csrc/hank_wide.h)
     assert same(aggw, agg)
     scale = np.abs(dagg).max()
     assert np.max(np.abs(daggw[:, :32] - dagg)) < 1e-12 + 1e-11 * scale      # same directions in another batch geometry
