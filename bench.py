@@ -551,7 +551,8 @@ def main(argv=None):
         step()
     hb.check()
     fence()
-    primal_before = hb.stats()["primal_sweeps"]
+    st_before = hb.stats()
+    primal_before = st_before["primal_sweeps"]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -561,6 +562,10 @@ def main(argv=None):
     # every timed step ran its primal sweep (the primal memo of the host-pointer entry must never reach the timed region)
     st_timed = hb.stats()
     assert st_timed["primal_sweeps"] - primal_before == args.steps and st_timed["primal_memo_hits"] == 0, st_timed
+    # ... on ONE schedule: a persistent sweep that could not form its groups moves the context to the launches silently (the host
+    # entries fall back by themselves, hank_check for the _dev entries) — a number measured across such a switch is not a measurement
+    if st_timed["fallbacks"] != st_before["fallbacks"] or st_timed["schedule"] != st_before["schedule"]:
+        raise SystemExit(f"bench.py: the context changed schedule during the timed region ({st_before} -> {st_timed}): {hb._lib.hank_last_error(hb._ctx).decode()}")
     tm = hb.last_timings()          # HIP events on the library's stream around each sweep (last step)
     # which sweeps the timed call ran: the dual-sweep launches (dual_*), or persistent sweeps (the Float64 backward sweep — with the
     # partials in it when the batch is one pass: k_xdual_back — then the tangent sweeps; the forward one carries D_t: k_xfwd<D,true>)
@@ -641,7 +646,13 @@ def main(argv=None):
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_launch_s,
                          "model_ceiling": model_ceiling(G, N, n_e),
                          "schedule": "xcd-persistent" if persistent else "launch-per-period",
+                         # measured per-wave issue and wait shares of that kernel (a separate rocprofv3 --pmc pass, same hash rule as traffic)
+                         "counters": (pmc or {}).get("counters"),
                          "note": "avg launch = HIP-event time of the sweep's kernels on the library's stream / launches"},
+            # hank_stats of the timed context: schedule in use (2 = auto, 1 = persistent forced, 0 = launches), fallbacks from the
+            # persistent sweeps to the launches (the run FAILS if one happens inside the timed region), primal sweeps the memo skipped
+            "hank_stats": {k: st_timed[k] for k in ("schedule", "fallbacks", "primal_memo_hits", "primal_sweeps", "sweep_launches")},
+            "tangent_family": hb.info()["last_tangent_family_name"],
             "whole_batch": {"B_alg_bytes": b_alg_batch, "achieved_GBs": b_alg_batch / (1e-3 * ms_per_step) / 1e9,
                             "frac_of_hbm_peak": b_alg_batch / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS},
             "sweeps_ms": {k: round(acc[k], 4) for k in acc}, "launches": launches,

@@ -173,29 +173,28 @@ def _lu_solver(J):
 
 
 _INV_CACHE = []         # [(J, apply)]
-_WARM = {"thread": None}
+_WARM = {"done": False}
 
 
 def warm_linear_solver(n_unknowns: int):
     """The device linear-algebra libraries behind `_device_inverse_solver` (rocSOLVER / rocBLAS through torch) take 0.15-0.35 s to
-    start the first time a process uses them (scripts/dev_inv_cost.py) — host time: shared objects and code objects being loaded.
-    A model with >= 2 000 unknowns will need them, so `find_ss` calls this where its own solve begins and the start-up passes
-    behind it in a background thread (one small inverse and one product on the device). Idempotent; a no-op without a GPU."""
-    if n_unknowns < 2000 or _WARM["thread"] is not None:
+    start the first time a process uses them (scripts/dev_inv_cost.py): shared objects and code objects being loaded. A model with
+    >= 2 000 unknowns will need them, so `find_ss` calls this BEFORE its own solve begins: one small inverse and one product on the
+    device, synchronously. (Round 4 ran it in a background thread beside the solve. The steady state's inner fixed points are
+    persistent sweeps that assume the process has the GPU to itself — a library kernel that lands between their workgroups can
+    keep a group from forming, and the context then moves to the per-period launches for good, silently: hank_stats' `fallbacks`.
+    The start-up is paid once per process either way; here it can no longer cost a schedule.) Idempotent; a no-op without a GPU."""
+    if n_unknowns < 2000 or _WARM["done"]:
         return
-
-    def run():
-        try:
-            import torch
-            if torch.cuda.is_available():
-                A = torch.eye(512, dtype=torch.float64, device="cuda") + 0.001
-                (torch.linalg.inv(A) @ A[:, :1]).cpu()
-        except Exception:       # noqa: BLE001 - a warm-up must never fail a solve
-            pass
-
-    import threading
-    _WARM["thread"] = threading.Thread(target=run, name="hank-linalg-warmup", daemon=True)
-    _WARM["thread"].start()
+    _WARM["done"] = True
+    try:
+        import torch
+        if torch.cuda.is_available():
+            A = torch.eye(512, dtype=torch.float64, device="cuda") + 0.001
+            (torch.linalg.inv(A) @ A[:, :1]).cpu()
+            torch.cuda.synchronize()
+    except Exception:       # noqa: BLE001 - a warm-up must never fail a solve
+        pass
 
 
 def _device_inverse_solver(J):
@@ -212,8 +211,6 @@ def _device_inverse_solver(J):
     if not (_INV_CACHE and _INV_CACHE[0][0] is J):
         import time
         t0 = time.perf_counter()
-        if _WARM["thread"] is not None:
-            _WARM["thread"].join()      # (the start-up, if it was begun early, must not run concurrently with the real inverse)
         A = J.toarray() if hasattr(J, "toarray") else np.asarray(J)
         dev = torch.device("cuda", torch.cuda.current_device())
         Ainv = torch.linalg.inv(torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(dev))

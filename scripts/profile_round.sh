@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra"
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
 SQ2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM"
+SQ3="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU"
 run_set() {   # $1 = tag, rest of the environment as set by the caller
   local T=$1
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/bench_kt_$T.log 2>&1 || { echo "kernel-trace pass failed"; tail -5 $O/bench_kt_$T.log; return 1; }
@@ -28,7 +29,7 @@ PY
   rm -rf $O/kt
   echo "kernel trace done ($T)"
   local n=0
-  for C in "FETCH_SIZE" "WRITE_SIZE" "$SQ1" "$SQ2"; do
+  for C in "FETCH_SIZE" "WRITE_SIZE" "$SQ1" "$SQ2" "$SQ3"; do
     n=$((n+1))
     local name=$(echo $C | awk '{print $1}'); [ $n -ge 3 ] && name="SQ$((n-2))"
     timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$name -o pmc -- python3 $R/bench.py $ARGS > $O/bench_${name}_$T.log 2>&1 || { echo "$name pass failed"; tail -5 $O/bench_${name}_$T.log; rm -rf $O/pmc_$name; continue; }

@@ -27,6 +27,49 @@ for k in ("k_fused_back", "k_fused_fwd", "k_xdual_back", "k_xfwd"):       # the 
         continue
     wl[k] = {"fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w, "note": note, "profile_tag": tag}
     found.append(k)
+
+
+def sq(counter, kernel, which):
+    """mean of an SQ counter per launch of `kernel` from the SQ pass `which` (None where the pass or the counter is missing)."""
+    f = root / f"{tag}_pmc_{which}_summary.txt"
+    if not f.exists():
+        return None
+    blocks = re.split(r"^(?=\S)", f.read_text(), flags=re.M)
+    for b in blocks:
+        if b.startswith(kernel + "<") or b.startswith(kernel + " "):
+            m = re.search(r"^\s+" + counter + r"\s+mean\s+([\d.]+)", b, re.M)
+            if m:
+                return float(m.group(1))
+    return None
+
+
+# measured issue and wait shares of the persistent Dual pass's kernels (the bench line prints them next to its model ceiling):
+# VALU wave-instructions per wave and period, the share of wave-cycles parked at s_waitcnt / a barrier, LDS bank conflicts
+P_HEADLINE = 299
+for k in found:
+    c = {}
+    waves, valu, wcyc, wany, winst = (sq(n, k, "SQ1") for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"))
+    conf, lact, wlds, vrd, vwr = (sq(n, k, "SQ2") for n in ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+    avalu, avmem = (sq(n, k, "SQ3") for n in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM"))
+    persistent = k.startswith("k_x")
+    if waves and valu:
+        c["valu_insts_per_wave" + ("_period" if persistent else "")] = valu / waves / (P_HEADLINE if persistent else 1)
+    if wcyc and wany is not None:
+        c["parked_frac"] = wany / wcyc
+    if wcyc and winst is not None:
+        c["issue_stall_frac"] = winst / wcyc
+    if lact and conf is not None:
+        c["lds_bank_conflict_frac"] = conf / lact
+    if wcyc and wlds is not None:
+        c["wait_lds_frac"] = wlds / wcyc
+    if waves and vrd is not None:
+        c["vmem_rd_per_wave" + ("_period" if persistent else "")] = vrd / waves / (P_HEADLINE if persistent else 1)
+    if wcyc and avalu is not None:
+        c["active_valu_frac"] = avalu / wcyc
+    if wcyc and avmem is not None:
+        c["active_vmem_frac"] = avmem / wcyc
+    c["source"] = f"profiles/{tag}_pmc_SQ1/SQ2/SQ3_summary.txt (rocprofv3 --pmc, per launch; SQ_* cycle counters are quad-cycles, ratios are unit-free)"
+    wl[k]["counters"] = c
 sys.path.insert(0, str(root.parent))
 from bench import kernel_source_sha16  # noqa: E402
 wl["kernel_source_sha16"] = kernel_source_sha16()

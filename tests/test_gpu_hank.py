@@ -103,6 +103,18 @@ def test_monetary_shock_converges(hank):
     assert out["impact"]["Y"] < 0 and out["impact"]["infl"] < 0
 
 
+def test_solve_above_2000_unknowns_keeps_the_persistent_schedule(hank):
+    """find_ss + NewtonRaphsonHANK with >= 2 000 unknowns (the size from which the device linear solver and its library warm-up
+    are used): no device work of the host layer may overlap a persistent sweep — the context must end on the schedule it started
+    on, with no fallback (the warm-up used to run in a background thread beside the steady state's sweeps)."""
+    from examples.solve_hank import solve
+    import hank_amd as h
+    out, x, m, ss = solve(130, 3, 300, shock=0.0025)           # 7 unknowns x 299 periods
+    assert out["residual_norm"] < 1e-8
+    st = h.household_block(m).stats()
+    assert st["fallbacks"] == 0 and st["schedule"] != 0, st
+
+
 def test_residual_layer_linearised_once_equals_the_dual_evaluation(hank):
     """LinearizedFunction.jvp through the sparse maps dR/dx, dR/dagg built once per x (one Dual evaluation of the compiled
     equations, colours = padded column mod (1 + max_lag + max_lead)) against the reference's way — the equations re-evaluated
