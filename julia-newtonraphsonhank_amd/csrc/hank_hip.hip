@@ -135,10 +135,12 @@ struct hank_ctx {
     struct { double *dpT = nullptr, *iota = nullptr, *E = nullptr, *Cp = nullptr, *F = nullptr, *Dv = nullptr; int N = 0; } fn;   // hank_fake_news workspace
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     // on-chip wide sweeps: 0 = never, 1 = auto (batches of at least wide_min directions), 2 = every batch (HANK_SCHEDULE=wide: tests)
-    int wide_mode = 0, wide_min = 184, num_cus = 256;
+    int wide_mode = 0, wide_min = 152, num_cus = 256, wide_r = 4;     // wide_r: rows per thread of the wide kernels (dev knob HANK_WIDE_R=2|4 at hank_create)
     size_t lds_max = 65536;
     char *rec_slab = nullptr;      // the record's ONE allocation
     size_t rec_bytes = 0;
+    int *d_ibw = nullptr;          // the wide backward sweep's bracket record (k_wide_prep), valid for the recorded primal or not
+    bool wprep_valid = false;
     std::list<WTan> wtans;         // most recently used first
     WTan *wcur = nullptr;
     std::vector<double> h_Pi, h_z;  // host copies (the wide sweeps take the mixing matrix as a kernel argument)
@@ -157,6 +159,7 @@ struct hank_ctx {
 
 static int fail(hank_ctx *ctx, int code, const char *fmt, ...);
 static void w_invalidate(hank_ctx *ctx) { for (WTan &t : ctx->wtans) t.valid = false; }
+static void w_new_primal(hank_ctx *ctx) { ctx->wprep_valid = false; }      // (the record is about to be rewritten)
 static void w_free_tan(WTan &w) {
     (void)hipFree(w.dxhh); (void)hipFree(w.dpol); (void)hipFree(w.dagg_cm);
     w = WTan();
@@ -748,7 +751,7 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullp
     ctx->launches[0] = ctx->launches[1] = 1;
     ctx->ev_valid[0] = true; ctx->ev_valid[1] = !skip_fwd;
     ctx->ev_valid[2] = ctx->ev_valid[3] = ctx->ev_valid[4] = ctx->ev_valid[5] = false;
-    ctx->primal_done = true;
+    ctx->primal_done = true; w_new_primal(ctx);
     X.src_valid = false;
     for (XTan &t : X.tans) t.valid = false;
     w_invalidate(ctx);
@@ -869,15 +872,21 @@ static bool w_ne_instantiated(int ne) {
 #undef X
     return false;
 }
-static int w_threads(const Consts &c) { return std::max(64, ((c.n_a + WIDE_R - 1) / WIDE_R + 63) / 64 * 64); }
+// geometry of the wide kernels (hank_wide.h): rows per thread 4 (workgroups of <= 512 threads) or 2 (<= 1024); which columns of the
+// state stay in registers follows from the register budget of each: all of them, except the forward kernel of the 2-row geometry
+struct WGeom { int R, maxt, kreg_b, kreg_f; };
+static WGeom w_geom(const hank_ctx *ctx) { return ctx->wide_r == 2 ? WGeom{2, 1024, 16, 7} : WGeom{4, 512, 16, 16}; }
+static int w_threads(const hank_ctx *ctx) { const WGeom g = w_geom(ctx); return std::max(64, ((ctx->c.n_a + g.R - 1) / g.R + 63) / 64 * 64); }
+static size_t w_lds(const hank_ctx *ctx) { const WGeom g = w_geom(ctx); return std::max(wide_lds_back(ctx->c, g.kreg_b), wide_lds_fwd(ctx->c, g.kreg_f)); }
 static bool w_supported(const hank_ctx *ctx) {
     const Consts &c = ctx->c;
-    return w_ne_instantiated(c.n_e) && w_threads(c) <= WIDE_MAXT && std::max(wide_lds_back(c), wide_lds_fwd(c)) <= ctx->lds_max &&
+    return w_ne_instantiated(c.n_e) && c.n_a <= WIDE_CS && w_lds(ctx) <= ctx->lds_max &&
            ctx->rec_bytes < 0x7fffffffull && (size_t)c.G * sizeof(double) < 0x7fffffffull;
 }
-// auto: a workgroup (= a direction) per CU and round; a round costs what ~184 directions cost the per-period launches (measured at
-// 2000x11, T=300: 15.1 ms per round at a recorded primal against 0.082 ms per direction), so the batch goes to the wide sweeps when
-// its last round is at least that full (N = 256, 512: yes; N = 128, 300: no). wide_min (HANK_WIDE_MIN) is that fill, in directions.
+// auto: a workgroup (= a direction) per CU and round; a round costs what ~150 directions cost the per-period launches (measured at
+// 2000x11, T=300: 11.9 ms per round at a recorded primal — 13.9 with all 256 CUs busy — against 0.082 ms per direction), so the
+// batch goes to the wide sweeps when its last round is at least that full (N = 160, 256, 512: yes; N = 128, 300: no). wide_min
+// (HANK_WIDE_MIN) is that fill, in directions.
 static bool use_wide(const hank_ctx *ctx, int N) {
     if (ctx->wide_mode == 2) return true;
     if (ctx->wide_mode != 1) return false;
@@ -885,32 +894,32 @@ static bool use_wide(const hank_ctx *ctx, int N) {
     return (long long)N * 256 >= (long long)rounds * ctx->wide_min * ctx->num_cus;      // (wide_min is quoted for a 256-CU chip)
 }
 
-template <int NE>
-static int w_launch_ne(hank_ctx *ctx, bool fwd, int N, const WideArgs &a) {
+template <int NE, int R, int MAXT, int KB, int KF>
+static int w_launch_geom(hank_ctx *ctx, bool fwd, int N, const WideArgs &a) {
     const Consts &c = ctx->c;
     WMat<NE> M;
     for (int k = 0; k < NE; k++)
         for (int e = 0; e < NE; e++) M.m[k * NE + e] = fwd ? ctx->h_Pi[k + NE * e] : ctx->h_Pi[e + NE * k];
     for (int e = 0; e < NE; e++) M.z[e] = ctx->h_z[e];
-    const dim3 grd((unsigned)N), blk((unsigned)w_threads(c));
+    const dim3 grd((unsigned)N), blk((unsigned)w_threads(ctx));
     if (fwd) {
-        const size_t lds = wide_lds_fwd(c);
-        HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_fwd<NE, WIDE_R, WIDE_MAXT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_wide_fwd<NE, WIDE_R, WIDE_MAXT>), grd, blk, lds, ctx->stream, a, M);
+        const size_t lds = wide_lds_fwd(c, KF);
+        HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_fwd<NE, R, MAXT, KF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_wide_fwd<NE, R, MAXT, KF>), grd, blk, lds, ctx->stream, a, M);
     } else {
-        const size_t lds = wide_lds_back(c);
+        const size_t lds = wide_lds_back(c, KB);
         if (c.diet) {
-            HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_back<NE, WIDE_R, WIDE_MAXT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_wide_back<NE, WIDE_R, WIDE_MAXT, true>), grd, blk, lds, ctx->stream, a, M);
+            HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_back<NE, R, MAXT, true, KB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_wide_back<NE, R, MAXT, true, KB>), grd, blk, lds, ctx->stream, a, M);
         } else {
-            HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_back<NE, WIDE_R, WIDE_MAXT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_wide_back<NE, WIDE_R, WIDE_MAXT, false>), grd, blk, lds, ctx->stream, a, M);
+            HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wide_back<NE, R, MAXT, false, KB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_wide_back<NE, R, MAXT, false, KB>), grd, blk, lds, ctx->stream, a, M);
         }
     }
     return HANK_OK;
 }
 static int w_launch(hank_ctx *ctx, bool fwd, int N, const WideArgs &a) {
-#define X(NEV) if (ctx->c.n_e == NEV) return w_launch_ne<NEV>(ctx, fwd, N, a);
+#define X(NEV) if (ctx->c.n_e == NEV) return ctx->wide_r == 2 ? w_launch_geom<NEV, 2, 1024, 16, 7>(ctx, fwd, N, a) : w_launch_geom<NEV, 4, 512, 16, 16>(ctx, fwd, N, a);
     HANK_WIDE_NE_LIST(X)
 #undef X
     return fail(ctx, HANK_ERR_BAD_ARG, "on-chip wide sweeps: n_e=%d is not instantiated", ctx->c.n_e);
@@ -957,13 +966,19 @@ static int w_run_tangent(hank_ctx *ctx, WTan *w, const double *d_dxhh) {
     hipStream_t s = ctx->stream;
     int rc = x_serialize_begin(ctx);        // (a persistent sweep of another context must not find the chip half full of these workgroups)
     if (rc) return rc;
+    if (!ctx->d_ibw) HIPC(ctx, dmalloc(&ctx->d_ibw, (size_t)c.P * c.G + 4));      // (before the kernel arguments are filled in)
     WideArgs a{};
     a.c = c; a.R = ctx->R; a.xhh = ctx->d_xhh; a.dxhh = d_dxhh; a.Ntot = w->N; a.n0 = 0; a.dpol = w->dpol; a.dagg = w->dagg_cm;
     a.rec = ctx->rec_slab;
     auto off = [&](const void *p) { return (unsigned)((const char *)p - ctx->rec_slab); };
     const Record &R = ctx->R;
-    a.o_s = off(R.s); a.o_kc = off(R.kc); a.o_A = off(R.A); a.o_B = off(R.B); a.o_u = off(R.u); a.o_v = off(R.v); a.o_ib = off(R.ib);
+    a.o_s = off(R.s); a.o_kc = off(R.kc); a.o_u = off(R.u); a.o_v = off(R.v); a.ibw = ctx->d_ibw;
     a.o_lwg = off(R.lwg); a.o_start = off(R.start); a.o_D = off(R.Dseq); a.o_pol = off(R.pol);
+    if (!ctx->wprep_valid) {                // once per recorded primal
+        const size_t npt = (size_t)c.P * c.G;
+        hipLaunchKernelGGL(k_wide_prep, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, s, R.ib, R.A, R.B, npt, ctx->d_ibw);
+        ctx->wprep_valid = true;
+    }
     HIPC(ctx, hipEventRecord(ctx->ev[3], s));
     rc = w_launch(ctx, false, w->N, a);
     if (rc) return rc;
@@ -1113,11 +1128,12 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     }
     // on-chip wide sweeps (hank_wide.h): "auto" sends tangent batches of at least wide_min directions to them (measured crossover,
     // DESIGN.md section 4); a forced schedule (launch | xcd) keeps its one implementation; HANK_SCHEDULE=wide sends every batch (tests)
+    if (const char *wr = getenv("HANK_WIDE_R")) ctx->wide_r = atoi(wr) == 2 ? 2 : 4;
     ctx->wide_mode = (w_supported(ctx) && !(se && (strcmp(se, "launch") == 0 || strcmp(se, "xcd") == 0))) ? 1 : 0;
     if (se && strcmp(se, "wide") == 0) {
         if (!w_supported(ctx))
             return fail(ctx, HANK_ERR_BAD_ARG, "HANK_SCHEDULE=wide: %dx%d, T=%d does not fit the on-chip wide sweeps (n_e instantiated: 2,3,4,5,7,11; n_a <= %d; %zu bytes of LDS per workgroup, the device has %zu)",
-                        c.n_a, c.n_e, ctx->T, WIDE_R * WIDE_MAXT, std::max(wide_lds_back(c), wide_lds_fwd(c)), ctx->lds_max);
+                        c.n_a, c.n_e, ctx->T, WIDE_CS, w_lds(ctx), ctx->lds_max);
         ctx->wide_mode = 2;
     }
     if (const char *wm = getenv("HANK_WIDE_MIN")) ctx->wide_min = std::max(1, atoi(wm));
@@ -1151,7 +1167,7 @@ int hank_destroy(hank_ctx *ctx) {
     for (WTan &t : ctx->wtans) w_free_tan(t);
     ctx->wtans.clear();
     ctx->wcur = nullptr;
-    (void)hipFree(ctx->rec_slab);
+    (void)hipFree(ctx->rec_slab); (void)hipFree(ctx->d_ibw);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
     (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 16; k++)
@@ -1238,7 +1254,7 @@ static int run_primal(hank_ctx *ctx, double *d_agg_out) {
     ctx->side_pending = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = true;
     ctx->ev_valid[4] = ctx->ev_valid[5] = false;
-    ctx->primal_done = true;
+    ctx->primal_done = true; w_new_primal(ctx);
     ctx->xw.src_valid = false; ctx->xw.rng_valid = false;
     for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     return HANK_OK;
@@ -1470,7 +1486,7 @@ static int run_fused(hank_ctx *ctx) {
     HIPC(ctx, hipEventRecord(ctx->ev[10], ctx->stream));
     ctx->ev_valid[4] = ctx->ev_valid[5] = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
-    ctx->primal_done = true;
+    ctx->primal_done = true; w_new_primal(ctx);
     ctx->xw.src_valid = false; ctx->xw.rng_valid = false;
     for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     w.valid = true;

@@ -32,11 +32,12 @@
 
 namespace hank {
 
-constexpr int WIDE_R = 4;          // wealth rows per thread
-constexpr int WIDE_MAXT = 512;     // threads per workgroup: 8 waves, 2 per SIMD -> 256 VGPRs per lane
-constexpr int WIDE_KREG = 16;      // columns of the state kept in registers; any beyond live in thread-private LDS slots (none at n_e <= 16:
-                                   // the single-buffered record stages below left room for the whole state)
-constexpr int wide_kl(int ne) { return ne > WIDE_KREG ? ne - WIDE_KREG : 0; }
+// Two geometries of the same kernels: R = 4 rows per thread in workgroups of up to 512 threads (8 waves, 2 per SIMD, 256 VGPRs per
+// lane) or R = 2 rows per thread in workgroups of up to 1024 (16 waves, 4 per SIMD, 128 VGPRs: more waves to put behind each other's
+// memory stalls, half the registers each). Either way a workgroup covers WIDE_CS = R * MAXT = 2048 rows.
+constexpr int WIDE_CS = 2048;      // row slots of a workgroup = slots of an exchanged LDS column
+// KREG = columns of the state kept in registers; any beyond live in thread-private LDS slots
+constexpr int wide_kl(int ne, int kreg) { return ne > kreg ? ne - kreg : 0; }
 // the mixing matrix as the kernel walks it — m[k*NE + e] = the coefficient of input column k in output column e (backward: Pi[e, k]
 // = P(e -> k), i.e. column-major Pi itself; forward: Pi[k, e] = P(k -> e), its transpose) — and the productivity grid. Passed BY
 // VALUE: the kernel-argument segment is read with scalar loads.
@@ -68,8 +69,10 @@ __device__ __forceinline__ void wide_mix(double (&x)[R][KR], double *lst, const 
 #pragma unroll
     for (int k = 0; k < NE; k++) {
         if (k + 1 < NE) {
+            // (the empty asm ties the loads of the next coefficient row to the LAST sum of the previous step, the scheduling barrier
+            // at the end of a step keeps the steps apart: loose, the scalar loads of a whole period line up at the top and spill)
             if (k == 0) asm volatile("" : "+s"(off) : "v"(x[0][0]));
-            else asm volatile("" : "+s"(off) : "v"(y[0][0]));
+            else asm volatile("" : "+s"(off) : "v"(y[R - 1][NE - 1]));
 #pragma unroll
             for (int e = 0; e < NE; e++) cf[(k + 1) & 1][e] = m[off + (k + 1) * NE + e];
             if (k + 1 >= KR) {
@@ -85,8 +88,9 @@ __device__ __forceinline__ void wide_mix(double (&x)[R][KR], double *lst, const 
         for (int q = 0; q < R; q++) {
             const double xk = k < KR ? x[q][k < KR ? k : 0] : xl[k & 1][q];
 #pragma unroll
-            for (int e = 0; e < NE; e++) y[q][e] = k == 0 ? cf[0][e] * xk : y[q][e] + cf[k & 1][e] * xk;
-        }
+            for (int e = 0; e < NE; e++) { y[q][e] = k == 0 ? cf[0][e] * xk : y[q][e] + cf[k & 1][e] * xk; asm volatile("" : "+v"(y[q][e])); }
+        }       // (every partial sum is pinned to its step: unpinned, all of a period's multiply-adds sink below the last step's loads)
+        __builtin_amdgcn_sched_barrier(0);
     }
     // (the results are pinned HERE: each has one use, inside a column's code, and the compiler would sink the whole sum — and
     // every coefficient, as a spilled scalar — down to it)
@@ -151,15 +155,16 @@ struct WideArgs {
     // the record is ONE allocation (hank_create): every array is reached through ONE buffer descriptor plus its byte offset from
     // `rec` (a descriptor is four scalar registers; eleven of them, next to the mixing's coefficient stream, spilled)
     const void *rec;
-    unsigned o_s, o_kc, o_A, o_B, o_u, o_v, o_ib, o_lwg, o_start, o_D, o_pol;
+    unsigned o_s, o_kc, o_u, o_v, o_lwg, o_start, o_D, o_pol;
+    const int *ibw;         // [P][G] bracket | (A == B == 0) << 31 (k_wide_prep)
 };
 
 // dynamic LDS of the two kernels: the exchanged column holds a slot for every row a thread may own (R * WIDE_MAXT >= n_a)
-static inline size_t wide_lds_back(const Consts &c) {
-    return sizeof(double) * (2 * (size_t)WIDE_R * WIDE_MAXT + 8 * (size_t)c.P + (size_t)wide_kl(c.n_e) * WIDE_R * WIDE_MAXT);
+static inline size_t wide_lds_back(const Consts &c, int kreg) {      // two columns of {ds, knot} pairs, the grid's spacings, the per-period inputs, the LDS-resident state columns
+    return sizeof(double) * (4 * (size_t)WIDE_CS + (size_t)WIDE_CS + 8 * (size_t)c.P + (size_t)wide_kl(c.n_e, kreg) * WIDE_CS);
 }
-static inline size_t wide_lds_fwd(const Consts &c) {
-    return sizeof(double) * (4 * (size_t)WIDE_R * WIDE_MAXT + 64 + (size_t)wide_kl(c.n_e) * WIDE_R * WIDE_MAXT) + sizeof(int) * ((size_t)c.P * c.n_e + 4);
+static inline size_t wide_lds_fwd(const Consts &c, int kreg) {
+    return sizeof(double) * (4 * (size_t)WIDE_CS + 64 + (size_t)wide_kl(c.n_e, kreg) * WIDE_CS) + sizeof(int) * ((size_t)c.P * c.n_e + 4);
 }
 
 // this thread's rows: two pairs of adjacent rows, pair j = rows 2 (j NT + tid), + 1. A lane whose pair lies beyond the grid reads
@@ -183,17 +188,23 @@ struct WideRows {
 // ---- backward: dV_t from dV_{t+1}; sequence X(P-1) Y(P-1) | X(P-2) Y(P-2) | ... (k_xtan_back's expressions) ------------------
 //   X: dE = Pi dV_{t+1} (lane-local); ds = kc dE - rho ((z_e dw + dtr) + s dr)           KrusellSmith.jl:59-62 under Dual
 //   Y: dg = A ds[ib] + B ds[ib+1] (through the LDS column); dV = u dr + v ((a dr + z_e dw + dtr) - dg)   :66-80
-template <int NE, int R, int MAXT, bool DIET>
+// RECORD DIET of this family: A and B are not read. The exchanged column carries the knot next to its partial ({ds, s} pairs), the
+// gathering lane has the two knots of its bracket with the two partials and rebuilds the weights egm_Y recorded — h = s_{i+1} - s_i,
+// f = (a - s_i) / h, sl = (a_{i+1} - a_i) / h, A = -sl (1 - f), B = -sl f (the division as a reciprocal with two Newton steps: a
+// rounding away from the recorded values) — or takes zeros where the record says both were zero (bit 31 of the bracket, k_wide_prep).
+// 16 of the 52 bytes a grid point and period costs this kernel's vector-memory path, for ~20 arithmetic instructions it has room for.
+template <int NE, int R, int MAXT, bool DIET, int KREG>
 __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
 #pragma clang fp contract(fast)
-    static_assert(R % 2 == 0, "rows come in adjacent pairs");
-    constexpr int KL = wide_kl(NE), KR = NE - KL, CS = R * MAXT;      // CS: slots of an exchanged column
+    static_assert(R % 2 == 0 && R * MAXT == WIDE_CS, "rows come in adjacent pairs; a workgroup covers WIDE_CS rows");
+    constexpr int KL = wide_kl(NE, KREG), KR = NE - KL, CS = R * MAXT;      // CS: slots of an exchanged column
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
     const int na = c.n_a, P = c.P, NT = blockDim.x, tid = threadIdx.x, G = c.G;
     const int n = A.n0 + blockIdx.x;
-    double *buf = xl;                       // [2][CS] the column being exchanged
-    double *uni = xl + 2 * (size_t)CS;      // [P][8]: rho_t, 1 + r_t, w_t, tr_t, dr_t, dw_t, dtr_t of this direction
+    double2 *buf = reinterpret_cast<double2 *>(xl);         // [2][CS] the column being exchanged: {ds, knot}
+    double *dash = xl + 4 * (size_t)CS;     // [CS] a[i+1] - a[i]
+    double *uni = dash + CS;                // [P][8]: rho_t, 1 + r_t, w_t, tr_t, dr_t, dw_t, dtr_t of this direction
     double *lst = uni + 8 * (size_t)P + tid;        // [KL][R][MAXT]: this thread's slots of the LDS-resident columns of the state (compile-time strides: immediate offsets)
     for (int k = tid; k < P; k += NT) {
         const double r = A.xhh[c.n_hh * k];
@@ -201,6 +212,7 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
         uni[8 * k] = 1.0 / (1.0 + r); uni[8 * k + 1] = 1.0 + r; uni[8 * k + 2] = A.xhh[c.n_hh * k + 1]; uni[8 * k + 3] = hh_tr(c, A.xhh, k);
         uni[8 * k + 4] = dx[0]; uni[8 * k + 5] = dx[1]; uni[8 * k + 6] = c.n_hh > 2 ? dx[2] : 0.0; uni[8 * k + 7] = 0.0;
     }
+    for (int k = tid; k < CS; k += NT) dash[k] = k + 1 < na ? c.a[k + 1] - c.a[k] : 1.0;
     WideRows<R> rw;
     rw.init(NT, tid, na);
     double xa[R];
@@ -214,12 +226,12 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
 #pragma unroll
         for (int k = 0; k < KL; k++) lst[(k * R + q) * MAXT] = 0.0;
     }
-    const __amdgpu_buffer_rsrc_t rs = wide_rsrc(A.rec);
+    const __amdgpu_buffer_rsrc_t rs = wide_rsrc(A.rec), rs_w = wide_rsrc(A.ibw);
     // The record of a column lives in ONE register stage; each group of its arrays is re-loaded for the NEXT column the moment the
     // current column has used it for the last time (the knots after the X half, ib / A / B after the gather, u / v after dV): every
     // load has a whole column's time to land, and the column's loads are issued at three places instead of one burst — the CU's
     // vector-memory path (what bounds this family: ~30 B/clk per CU from L2) keeps working while the waves do arithmetic.
-    struct Stage { double s[R], kc[DIET ? 1 : R], cA[R], cB[R], cu[R], cv[R]; int ib[R]; } S;
+    struct Stage { double s[R], kc[DIET ? 1 : R], cu[R], cv[R]; int ib[R]; } S;
     auto load_X = [&](int so) {
 #pragma unroll
         for (int j = 0; j < R / 2; j++) {
@@ -230,10 +242,8 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
     auto load_Y1 = [&](int so) {
 #pragma unroll
         for (int j = 0; j < R / 2; j++) {
-            const wv2u iq = wide_ld2i(rs, rw.o4[j], A.o_ib + so * 4);
+            const wv2u iq = wide_ld2i(rs_w, rw.o4[j], so * 4);
             S.ib[2 * j] = (int)iq.x; S.ib[2 * j + 1] = (int)iq.y;
-            wide_ld2d<0>(rs, rw.o8[j], A.o_A + so * 8, S.cA[2 * j], S.cA[2 * j + 1]);
-            wide_ld2d<0>(rs, rw.o8[j], A.o_B + so * 8, S.cB[2 * j], S.cB[2 * j + 1]);
         }
     };
     auto load_Y2 = [&](int so) {
@@ -262,7 +272,7 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
             const int last = e + 1 == NE;
             const int son = (last ? (t > 0 ? t - 1 : 0) : t) * G + (last ? 0 : e + 1) * na + zt;      // the next column (of the next period behind the last)
             const double ze = M.z[e], wz = w * ze + tr, zd = ze * dw + dtr;
-            double *const col = buf + pb * CS;
+            double2 *const col = buf + pb * CS;
             double ds[R];
 #pragma unroll
             for (int q = 0; q < R; q++) {
@@ -272,18 +282,25 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
                 ds[q] = kc * dE - rho * (zd + S.s[q] * dr);
                 wide_pin(ds[q]);
             }
+#pragma unroll
+            for (int q = 0; q < R; q++) col[rw.row[q]] = make_double2(ds[q], S.s[q]);
             __builtin_amdgcn_sched_barrier(0);      // (the loads must not be scheduled above the last use of the registers they refill)
             load_X(son);
-#pragma unroll
-            for (int j = 0; j < R / 2; j++) *reinterpret_cast<double2 *>(col + rw.row[2 * j]) = make_double2(ds[2 * j], ds[2 * j + 1]);
             WSTAMP(0, t, 2 + 4 * e);
             xlds_barrier();
             WSTAMP(0, t, 3 + 4 * e);
             double dg[R];
 #pragma unroll
             for (int q = 0; q < R; q++) {
-                const double d0 = col[S.ib[q]], d1 = col[S.ib[q] + 1];
-                dg[q] = S.cA[q] * d0 + S.cB[q] * d1;
+                const int i = S.ib[q] & 0x7fffffff;
+                const double2 c0 = col[i], c1 = col[i + 1];     // {ds, knot} at the bracket's two ends
+                const double h = c1.y - c0.y;
+                double rh = __builtin_amdgcn_rcp(h);            // 1 / h: hardware estimate + two Newton steps
+                rh = rh + rh * (1.0 - h * rh);
+                rh = rh + rh * (1.0 - h * rh);
+                const double f = (xa[q] - c0.y) * rh, sl = dash[i] * rh;
+                const double wA = S.ib[q] < 0 ? 0.0 : -sl * (1.0 - f), wB = S.ib[q] < 0 ? 0.0 : -sl * f;
+                dg[q] = wA * c0.x + wB * c1.x;
                 wide_pin(dg[q]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -315,11 +332,11 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
 //   dD_t = dD_mid Pi (lane-local);  dagg_t = sum dpol_t D_t + sum pol_t dD_t  (post-transition D_t, ForwardIteration.jl:301-307)
 // The second sum of period t is taken one period later, when dD_t is walked as the source of period t + 1 (its rows are in
 // registers then, and pol_t is one more coalesced load of that walk); the last period's in an epilogue.
-template <int NE, int R, int MAXT>
+template <int NE, int R, int MAXT, int KREG>
 __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
 #pragma clang fp contract(fast)
-    static_assert(R % 2 == 0, "rows come in adjacent pairs");
-    constexpr int KL = wide_kl(NE), KR = NE - KL, CS = R * MAXT;
+    static_assert(R % 2 == 0 && R * MAXT == WIDE_CS, "rows come in adjacent pairs; a workgroup covers WIDE_CS rows");
+    constexpr int KL = wide_kl(NE, KREG), KR = NE - KL, CS = R * MAXT;
     constexpr int NWM = MAXT / 64;                          // wave slots of the per-wave sums (the slots of waves that do not exist stay zero)
     extern __shared__ __attribute__((aligned(16))) double xl[];
     const Consts &c = A.c;
@@ -484,6 +501,13 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
         for (int k = 0; k < NWM; k++) v += aggred[(P & 1) * 16 + k];
         outn[P - 1] = v;
     }
+}
+
+// once per recorded primal: the bracket with ONE bit of what the interpolation weights held — "both zero" (flat extrapolation, a
+// blocked max rule: KrusellSmith.jl:71-76). k_wide_back rebuilds A and B from the exchanged knots and reads this instead of them.
+__global__ void k_wide_prep(const int *__restrict__ ib, const double *__restrict__ A, const double *__restrict__ B, size_t n, int *__restrict__ ibw) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ibw[i] = ib[i] | ((A[i] == 0.0 && B[i] == 0.0) ? (int)0x80000000 : 0);
 }
 
 // (G, P, N) col-major export of the wide layout dpol[P][N][G]

@@ -75,7 +75,11 @@ def timing(Ns, n_a=2000, n_e=11, T=300):
     dev = torch.device("cuda", 0)
     d_x = torch.from_numpy(np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()).to(dev)
     res = {}
-    for sched, env in (("wide", {}), ("auto", {"HANK_WIDE_MIN": 100000})):
+    variants = (("wide", {}), ("wide", {"HANK_WIDE_R": 2}), ("auto", {"HANK_WIDE_MIN": 100000}))
+    if os.environ.get("DEV_WIDE_ONLY"):
+        variants = variants[:2]
+    for sched, env in variants:
+        sched_name = sched + ("_r2" if env.get("HANK_WIDE_R") == 2 else "")
         hb = block(m, sched, **env)
         hb.set_boundary(ss.value, ss.D)
         for N in Ns:
@@ -98,13 +102,14 @@ def timing(Ns, n_a=2000, n_e=11, T=300):
                 hb.jvp_dev(d_dx.data_ptr(), N, d_out.data_ptr())
             hb.sync()
             elj = (time.perf_counter() - t0) / reps
-            res[(sched, N)] = d_out.cpu().numpy().copy()
-            print(f"{sched:5s} N={N:4d}: primal_jvp {1e3 * el:7.2f} ms = {N / el:8.0f} JVPs/s | jvp at recorded primal {1e3 * elj:7.2f} ms = {N / elj:8.0f} JVPs/s | "
+            res[(sched_name, N)] = d_out.cpu().numpy().copy()
+            print(f"{sched_name:7s} N={N:4d}: primal_jvp {1e3 * el:7.2f} ms = {N / el:8.0f} JVPs/s | jvp at recorded primal {1e3 * elj:7.2f} ms = {N / elj:8.0f} JVPs/s | "
                   + " ".join(f"{k2}={v['ms']:.2f}" for k2, v in tm.items() if v['ms'] > 0) + f" | {hb.info()['last_tangent_family_name']}", flush=True)
         hb.close()
     for N in Ns:
-        a, b = res[("wide", N)], res[("auto", N)]
-        print(f"   N={N}: wide vs default dagg rel {rel(a, b):.2e}")
+        for other in ("wide_r2", "auto"):
+            if (other, N) in res:
+                print(f"   N={N}: wide vs {other} dagg rel {rel(res[('wide', N)], res[(other, N)]):.2e}")
 
 
 if __name__ == "__main__":
