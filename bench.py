@@ -594,7 +594,15 @@ def main(argv=None):
         # the policy partials of ONE period for N directions: G*8*N algorithmic bytes
         # (B_alg = 2*P*G*8*(1+N) per batch = G*8 bytes per (sweep, period, direction)).
         persistent = split_keys and launches.get("tangent_forward", P) < P
-        if persistent and not args.split and acc.get("tangent_backward", 0.0) < 0.05:
+        wide = hb.info()["last_tangent_family_name"] == "on-chip-wide"
+        if wide:
+            # the on-chip wide sweeps (csrc/hank_wide.h): one workgroup per direction, ONE launch per sweep; a launch moves the policy
+            # partials of every period and direction once (written by k_wide_back, read by k_wide_fwd): P*G*8*N bytes. The Float64
+            # sweeps run before them as XCD-local persistent sweeps and are part of ms_per_step.
+            dom = max(("tangent_backward", "tangent_forward"), key=lambda k: acc[k])
+            kname = {"tangent_backward": "k_wide_back", "tangent_forward": "k_wide_fwd"}[dom]
+            bytes_per_launch = P * G * 8 * N
+        elif persistent and not args.split and acc.get("tangent_backward", 0.0) < 0.05:
             # the persistent Dual pass: ONE launch per sweep, value and partials together in both (k_xdual_back writes the policy
             # and the policy partials of every period, k_xfwd<D, true> reads them): P*G*8*(1+N) algorithmic bytes per launch
             dom = max(("primal_backward", "tangent_forward"), key=lambda k: acc[k])
@@ -645,7 +653,7 @@ def main(argv=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_stale": traffic_stale, "traffic_detail": pmc,
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": 1e6 * avg_launch_s,
                          "model_ceiling": model_ceiling(G, N, n_e),
-                         "schedule": "xcd-persistent" if persistent else "launch-per-period",
+                         "schedule": "on-chip-wide" if wide else ("xcd-persistent" if persistent else "launch-per-period"),
                          # measured per-wave issue and wait shares of that kernel (a separate rocprofv3 --pmc pass, same hash rule as traffic)
                          "counters": (pmc or {}).get("counters"),
                          "note": "avg launch = HIP-event time of the sweep's kernels on the library's stream / launches"},
