@@ -444,9 +444,14 @@ def devicegroup_main(args):
         bufs.append((torch.from_numpy(xf).to(dev), torch.from_numpy(rng.standard_normal(2 * P * N)).to(dev),
                      torch.empty(P, dtype=torch.float64, device=dev), torch.empty(P * N, dtype=torch.float64, device=dev), st))
 
+    from hank_amd import hip as _hip
+    d_all = torch.empty(len(blocks) * P * N, dtype=torch.float64, device=torch.device("cuda", 0))
+
     def step():
         for hb, (dx_, dy_, ag_, out_, _) in zip(blocks, bufs):
             hb.primal_jvp_dev(dx_.data_ptr(), dy_.data_ptr(), N, ag_.data_ptr(), out_.data_ptr())
+        # the (P, N) blocks of all GPUs assembled in GPU 0's memory: peer copies over xGMI behind each context's sweeps (hank_gather_columns)
+        _hip.gather_columns(blocks, [b[3].data_ptr() for b in bufs], [N] * len(blocks), d_all.data_ptr())
 
     def fence():
         for hb in blocks:
@@ -469,8 +474,10 @@ def devicegroup_main(args):
            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": args.workload, "grid": f"{n_a}x{n_e}", "T": T, "tangents_per_gpu": N,
-                      "step": "1 dual pass per GPU: primal + N tangents (hank_primal_jvp_dev), no collective",
-                      "parallelism": f"one process, one context per GPU (hank_create_on) x{len(blocks)}"}}
+                      "step": "1 dual pass per GPU: primal + N tangents (hank_primal_jvp_dev), the column blocks gathered on GPU 0 over xGMI (hank_gather_columns)",
+                      "parallelism": f"one process, one context per GPU (hank_create_on) x{len(blocks)}"},
+           # (a context that lost its persistent schedule while other processes still held the GPUs would show here, not as a slower number)
+           "hank_stats": [{k: hb.stats()[k] for k in ("schedule", "fallbacks")} for hb in blocks]}
     print(json.dumps(out), flush=True)
     for hb in blocks[1:]:
         hb.close()
@@ -691,7 +698,7 @@ def main(argv=None):
                 r = subprocess.run(cmd, env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=600)
                 line = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 dg = json.loads(line[-1]) if (r.returncode == 0 and line) else {"error": (r.stderr or r.stdout)[-300:]}
-                out.setdefault("extra", {})["devicegroup"] = {k: dg[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "config", "error") if k in dg}
+                out.setdefault("extra", {})["devicegroup"] = {k: dg[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "config", "hank_stats", "error") if k in dg}
             except Exception as e:      # noqa: BLE001
                 out.setdefault("extra", {})["devicegroup"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(out), flush=True)

@@ -83,6 +83,15 @@ int hank_create(const hank_model *model, hank_ctx **out);   /* on the calling th
  * point makes its context's device current for the call and restores the caller's, so ONE host thread can keep all of a
  * node's contexts busy through the *_dev entries ("one process, eight GPUs"). */
 int hank_create_on(const hank_model *model, int32_t device, hank_ctx **out);
+/* hank_gather_columns: a tangent batch sharded by columns over one context per GPU (hank_create_on), assembled in ONE GPU's memory
+ * over xGMI — what a single-process host (the Julia reference is one) needs in place of the RCCL all-gather of the one-process-per-
+ * GPU form; `JVP(func, primal, tangent)` (GeneralStructures.jl:542-550) is linear in `tangent`, so the columns of a batch are
+ * independent. ctxs[0] receives. d_blocks[k]: device pointer on ctxs[k]'s device of its (P, N_k[k]) column-major block, as written
+ * by hank_jvp_dev / hank_primal_jvp_dev on ctxs[k]; d_out: (P, sum N_k) column-major on ctxs[0]'s device, the blocks in order.
+ * Asynchronous: every block is copied on its OWN context's stream behind the sweeps that produce it (hipMemcpyPeerAsync from the
+ * source device, peer access enabled on first use; a plain device copy where both contexts share a device) and ctxs[0]'s stream
+ * waits for all of them: hank_sync(ctxs[0]) — or work enqueued on its stream — sees the assembled matrix. */
+int hank_gather_columns(hank_ctx *const *ctxs, int32_t n, const double *const *d_blocks, const int32_t *N_k, double *d_out);
 int hank_destroy(hank_ctx *ctx);
 const char *hank_last_error(const hank_ctx *ctx); /* never NULL; "" when the last call succeeded  */
 int hank_n_hh(const hank_ctx *ctx);               /* household inputs per period (KS: 2)          */

@@ -1684,6 +1684,37 @@ int hank_stats(hank_ctx *ctx, int64_t out[8]) {
     return HANK_OK;
 }
 
+int hank_gather_columns(hank_ctx *const *ctxs, int32_t n, const double *const *d_blocks, const int32_t *N_k, double *d_out) {
+    if (!ctxs || n < 1 || !ctxs[0]) return HANK_ERR_BAD_ARG;
+    hank_ctx *c0 = ctxs[0];
+    if (!d_blocks || !N_k || !d_out) return fail(c0, HANK_ERR_BAD_ARG, "hank_gather_columns: null pointer");
+    const size_t P = c0->c.P;
+    size_t col = 0;
+    for (int k = 0; k < n; k++) {
+        hank_ctx *ck = ctxs[k];
+        if (!ck || ck->c.P != c0->c.P || N_k[k] < 0 || (N_k[k] > 0 && !d_blocks[k])) return fail(c0, HANK_ERR_BAD_ARG, "hank_gather_columns: bad block %d", k);
+        const size_t bytes = sizeof(double) * P * (size_t)N_k[k];
+        double *dst = d_out + P * col;
+        col += (size_t)N_k[k];
+        if (bytes == 0) continue;
+        ENTER(ck);                          // the copy is enqueued on the SOURCE context's stream, behind the sweeps that write the block
+        if (ck->device == c0->device) {
+            HIPC(c0, hipMemcpyAsync(dst, d_blocks[k], bytes, hipMemcpyDeviceToDevice, ck->stream));
+        } else {
+            const hipError_t pe = hipDeviceEnablePeerAccess(c0->device, 0);      // (from the source device: it writes into device 0's memory over xGMI)
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return fail(c0, HANK_ERR_NO_DEVICE, "no peer access from device %d to device %d (%s)", ck->device, c0->device, hipGetErrorString(pe)); }
+            (void)hipGetLastError();
+            HIPC(c0, hipMemcpyPeerAsync(dst, c0->device, d_blocks[k], ck->device, bytes, ck->stream));
+        }
+        if (ck != c0 && ck->stream != c0->stream) {
+            HIPC(c0, hipEventRecord(ck->ev_stream, ck->stream));
+            HIPC(c0, hipStreamWaitEvent(c0->stream, ck->ev_stream, 0));
+        }
+    }
+    c0->errmsg[0] = 0;
+    return HANK_OK;
+}
+
 int hank_info(hank_ctx *ctx, int64_t out[8]) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
     out[0] = ctx->last_tan; out[1] = ctx->wide_mode; out[2] = ctx->wide_min; out[3] = w_supported(ctx) ? 1 : 0;

@@ -23,7 +23,7 @@ HANK_VF_KRUSELL_SMITH = 0
 
 # the symbols include/hank_hip.h declares (tests check that every one is exported)
 ABI_SYMBOLS = (
-    "hank_create", "hank_create_on", "hank_destroy", "hank_last_error", "hank_n_hh", "hank_set_stream", "hank_sync",
+    "hank_create", "hank_create_on", "hank_gather_columns", "hank_destroy", "hank_last_error", "hank_n_hh", "hank_set_stream", "hank_sync",
     "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
     "hank_primal_jvp", "hank_primal_jvp_dev",
     "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
@@ -80,6 +80,7 @@ def load_library() -> C.CDLL:
     lib.hank_create.argtypes = [C.POINTER(hank_model), C.POINTER(vp)]
     lib.hank_create_on.argtypes = [C.POINTER(hank_model), i32, C.POINTER(vp)]
     lib.hank_destroy.argtypes = [vp]
+    lib.hank_gather_columns.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(i32), vp]
     lib.hank_last_error.argtypes = [vp]
     lib.hank_last_error.restype = C.c_char_p
     lib.hank_n_hh.argtypes = [vp]
@@ -120,6 +121,20 @@ def device_available() -> bool:
         return bool(load_library().hank_device_available())
     except (RuntimeError, OSError):
         return False
+
+
+def gather_columns(blocks, d_block_ptrs, N_k, d_out_ptr: int):
+    """hank_gather_columns: the (P, N_k) column blocks the contexts `blocks` hold in their own GPUs' memory (device pointers
+    `d_block_ptrs`, as written by jvp_dev / primal_jvp_dev) assembled as one (P, sum N_k) matrix at `d_out_ptr` on blocks[0]'s device
+    — over xGMI where the devices differ. Asynchronous: blocks[0].sync() before reading."""
+    lib = load_library()
+    n = len(blocks)
+    ctxs = (C.c_void_p * n)(*[b._ctx for b in blocks])
+    ptrs = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in d_block_ptrs])
+    nk = (C.c_int32 * n)(*[int(v) for v in N_k])
+    rc = lib.hank_gather_columns(ctxs, n, ptrs, nk, C.c_void_p(int(d_out_ptr)))
+    if rc != HANK_OK:
+        raise _ERR_CLASSES.get(rc, HankHIPError)(rc, lib.hank_last_error(blocks[0]._ctx).decode())
 
 
 def _f(x, shape=None) -> np.ndarray:

@@ -116,6 +116,26 @@ class DeviceGroup:
         parts = self._each(lambda b, lo, hi: b.jvp(y[:, :, lo:hi]) if hi > lo else np.empty((y.shape[1], 0)), bounds)
         return np.concatenate(parts, axis=1)
 
+    def jvp_dev(self, d_y_blocks, N_k):
+        """the same partition with everything on the devices: GPU g's tangent columns are already in its memory (`d_y_blocks[g]`: a
+        torch tensor of (n_hh, P, N_k[g]) column-major values on that device), every context runs its sweeps asynchronously, and
+        the (P, N_k[g]) results are assembled in devices[0]'s memory by hank_gather_columns — peer copies over xGMI, no host buffer,
+        no second process. Returns the (P, sum N_k) column-major matrix as a flat torch tensor on devices[0] (synchronised)."""
+        import torch
+        from . import hip
+        P = self.blocks[0].P
+        outs = []
+        for b, d, dy, nk in zip(self.blocks, self.devices, d_y_blocks, N_k):
+            o = torch.empty(P * int(nk), dtype=torch.float64, device=torch.device("cuda", d))
+            if nk:
+                b.jvp_dev(dy.data_ptr(), int(nk), o.data_ptr())
+            outs.append(o)
+        full = torch.empty(P * int(sum(N_k)), dtype=torch.float64, device=torch.device("cuda", self.devices[0]))
+        hip.gather_columns(self.blocks, [o.data_ptr() for o in outs], N_k, full.data_ptr())
+        self.blocks[0].sync()
+        self._keep = outs                    # (the blocks must outlive the copies)
+        return full
+
     def close(self):
         for b in self.blocks[1:]:
             b.close()

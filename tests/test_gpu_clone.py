@@ -55,6 +55,16 @@ def test_create_on_a_named_device_and_device_group(hank):
     np.testing.assert_array_equal(g.primal(x[2:4]), a0)
     dg = g.jvp(y)               # columns [0, 4) on the first context, [4, 7) on the second
     assert np.max(np.abs(dg - d0)) <= 1e-13 * np.abs(d0).max()
+    # the same partition assembled ON THE DEVICE (hank_gather_columns; on this box the "peer" is the same GPU): the host assembly, bit for bit
+    import torch
+    from hank_amd.parallel import shard_bounds
+    bounds = [shard_bounds(7, 2, k) for k in range(2)]
+    dev = torch.device("cuda", 0)
+    dy = [torch.from_numpy(np.asfortranarray(y[:, :, lo:hi]).reshape(-1, order="F").copy()).to(dev) for lo, hi in bounds]
+    full = g.jvp_dev(dy, [hi - lo for lo, hi in bounds])
+    np.testing.assert_array_equal(full.cpu().numpy().reshape((P, 7), order="F"), dg)
+    with pytest.raises(hank.HankHIPError):          # a block pointer that is missing is refused, nothing is copied
+        hank.hip.gather_columns(g.blocks, [0, 0], [4, 3], full.data_ptr())
     g.close(); hb1.close(); hb0.close()
 
 
