@@ -512,7 +512,8 @@ static size_t x_lds_dual_back(const Consts &c, int D) {
 // k_xfwd with NSL live slots (the D partials + the value): tile, Pi, {source range, clamped prefix} and source members of every period
 static size_t x_lds_fwd(const Consts &c, int NSL) {
     const int SLt = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);      // XSlots<NSL>::SL
-    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e) + sizeof(int) * ((size_t)c.P * c.n_e + c.P) + 64;
+    const int NAP = NSL == 1 ? 1 : ((NSL + 1) / 2) * 2;        // the aggregate's terms per lane (k_xfwd: aggsh)
+    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + 1 + 2 * (size_t)c.n_e * 64 * NAP) + sizeof(int) * ((size_t)c.P * c.n_e + c.P) + 64;
 }
 // the grid fits the XCD-local schedule: a 63-row slab per CU of an XCD, and the Float64 sweeps' LDS (which holds the
 // per-period inputs of the WHOLE horizon) fits a workgroup
@@ -740,7 +741,7 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullp
     }
     HIPC(ctx, hipEventRecord(ctx->ev[2], s));
     if (!skip_fwd) {
-        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact * c.n_e, 1, ctx->d_agg);
+        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact, 1, ctx->d_agg);
         hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
     }
     HIPC(ctx, hipGetLastError());
@@ -801,7 +802,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_bac
     }
     HIPC(ctx, hipEventRecord(ctx->ev[4], s));
     HIPC(ctx, hipEventRecord(ctx->ev[7], s));
-    const int nb = X.Sact * c.n_e;
+    const int nb = X.Sact;                  // (one row of partials per member: the sync wave sums a member's columns)
     for (int p = 0; p < np; p++) {
         const XPass &ps = w->passes[p];
         fa.sy = X.sync + 2 + 2 * p + 1; fa.groups = ps.groups; fa.dpol = w->dpol + ps.dpol_off;
@@ -809,7 +810,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_bac
         if (v) { fa.D0 = ctx->d_ss_D; fa.Dvirt = X.Dvirt; fa.aggpart = X.aggpart; }
         x_launch_fwd(X, ps.D, v, grd, blkF, x_lds_fwd(c, ps.D + (v ? 1 : 0)), s, fa);
         if (v) {
-            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact * c.n_e, 1, ctx->d_agg);
+            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact, 1, ctx->d_agg);
             hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
         }
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));

@@ -349,7 +349,9 @@ __device__ __forceinline__ void xtile_store_n(double *t, const double *v) {    /
     if (NS & 1) t[NS - 1] = v[NS - 1];
 }
 // out[s] = sum_k P[k*ps] * tile[k][lane][s], k ascending, first term unrounded-added (same order as mix_sum)
-template <int SL, int NS>
+// FMA: the forward sweeps (round 5) fuse the multiply-adds — a rounding away from the launches' sums, half the instructions of the
+// mixing (the library is built with -ffp-contract=off: a sum written p * v + acc is two instructions)
+template <int SL, int NS, bool FMA = false>
 __device__ __forceinline__ void xtile_mix(const double *tl, const double *P, int ps, int ne, double *out) {
     const int ks = 64 * SL;
 #pragma unroll 4
@@ -362,13 +364,13 @@ __device__ __forceinline__ void xtile_mix(const double *tl, const double *P, int
         }
         const double p = P[k * ps];
 #pragma unroll
-        for (int q = 0; q < NS; q++) out[q] = k == 0 ? p * v[q] : out[q] + p * v[q];
+        for (int q = 0; q < NS; q++) out[q] = k == 0 ? p * v[q] : (FMA ? __builtin_fma(p, v[q], out[q]) : out[q] + p * v[q]);
     }
 }
 
 // the same with the column of Pi held in registers (16 unrolled steps, the ones beyond n_e predicated off): no LDS read for
 // the coefficient, and every tile read of the pass can be in flight at once
-template <int SL, int NS>
+template <int SL, int NS, bool FMA = false>
 __device__ __forceinline__ void xtile_mix_reg(const double *tl, const double (&pr)[16], int ne, double *out) {
     const int ks = 64 * SL;
 #pragma unroll
@@ -381,7 +383,7 @@ __device__ __forceinline__ void xtile_mix_reg(const double *tl, const double (&p
                 for (int q = 0; q < (NS + 1) / 2; q++) { const double2 d = reinterpret_cast<const double2 *>(tl + (size_t)k * ks)[q]; v[2 * q] = d.x; v[2 * q + 1] = d.y; }
             }
 #pragma unroll
-            for (int q = 0; q < NS; q++) out[q] = k == 0 ? pr[k] * v[q] : out[q] + pr[k] * v[q];
+            for (int q = 0; q < NS; q++) out[q] = k == 0 ? pr[k] * v[q] : (FMA ? __builtin_fma(pr[k], v[q], out[q]) : out[q] + pr[k] * v[q]);
         }
     }
 }
@@ -1150,8 +1152,8 @@ struct XSweepFwdArgs {
     const double *dpol;         // D > 0: [P][groups][G][D]
     int groups;
     double *Dvirt;              // VAL: [P][n_e][64] the mass kept on the virtual rows (k_xfix_D)
-    double *aggpart;            // VAL: [P][members*n_e]
-    double *daggpart;           // D > 0: [P][members*n_e][XG*D]
+    double *aggpart;            // VAL: [P][members]
+    double *daggpart;           // D > 0: [P][members][XG*D]
     const int *src;             // [P][members] lo | hi << 8 | (some column clamped) << 16 | (member 0 records row 0's full mass) << 17 | units << 18
     const int2 *units;          // [P][members][XUCAP] {e | ja << 4 | cnt << 16, ta | tb << 8 | nv << 16}
     int all_members;            // dev knob: every period waits for every member
@@ -1159,6 +1161,7 @@ struct XSweepFwdArgs {
 
 template <int D, bool VAL, int MAXT>
 __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
+#pragma clang fp contract(fast)                         // (round 5) fused multiply-adds in this kernel (the mixing: xtile_mix<.., true>)
     constexpr int NSL = D + (VAL ? 1 : 0);              // live slots: the D partials, then the value
     constexpr int SP = XSlots<NSL>::SP, SL = XSlots<NSL>::SL;
     constexpr int IV = D;                               // the value's slot
@@ -1170,7 +1173,12 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     const int ne = c.n_e, na = c.n_a, P = c.P, G = c.G;
     double *tile = xl;                                  // [ne][64][SL]
     double *Pish = tile + (size_t)SL * ne * 64;         // [ne*ne] (read when !PIREG)
-    int *closh = reinterpret_cast<int *>(Pish + ne * ne);       // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
+    // (round 5) the aggregate's terms of a period, per lane: the column waves leave them here and the SYNC wave — idle between its
+    // polls — sums them over the columns and the lanes one period later. As eleven waves' own reductions they were 105 of the 562
+    // VALU instructions a wave issues per period, three waves deep on a SIMD.
+    constexpr int NAP = NSL == 1 ? 1 : ((NSL + 1) / 2) * 2;                 // terms per lane (padded to 16-byte pairs)
+    double *aggsh = Pish + ((ne * ne + 1) & ~1);        // [2][ne][64][NAP]
+    int *closh = reinterpret_cast<int *>(aggsh + 2 * (size_t)ne * 64 * NAP);       // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
     int *srcsh = closh + (size_t)P * ne;                // [P]
     int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
@@ -1289,20 +1297,27 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         ud[1] = udv[1] ? make_int2(__builtin_amdgcn_readfirstlane(udn[1].x), __builtin_amdgcn_readfirstlane(udn[1].y)) : make_int2(0, 0);
     };
     // The loads of the NEXT period — its two units' records, the own-row record, the descriptors of the period after — are cold
-    // lines of the record (2.4 us from HBM under this load) and vector-memory waits are in order: behind an ordinary drain
-    // (vmcnt(0) before the group barrier) they cost their whole latency every period. They are therefore issued AFTER the
-    // period's last store, as a batch of exactly XFWD_NLD instructions, every one of them unconditional, and the drain waits
-    // with vmcnt(XFWD_NLD): everything older than the batch — the stores — has completed, the batch itself stays in flight
-    // through the publish, the next poll and the next state loads (tests/test_isa_hazards.py counts the instructions between
-    // the two markers in the ISA against the immediate).
+    // lines of the record (2.4 us from HBM under this load) and vector-memory waits are in order. Round 5 splits them in two:
+    //  * the UNIT batch (the two units' records, the descriptors of the period after) is issued BEFORE the mixing, as soon as the
+    //    tile is complete: the stamps of round 4's single batch showed where its time went — not in latency but in ISSUE: twelve
+    //    waves x 17 loads through one CU's vector-memory path took 2.4 us, every member's flag waited for the slowest wave's last
+    //    load to be accepted, and the mixing (2 us of LDS and arithmetic that needs no memory path) sat in front of it, idle on
+    //    that path. Issued here they are accepted while the waves mix, and have landed when the period's stores are drained;
+    //  * the OWN-ROW batch (policy, policy partials, lottery weights of this lane's row: their registers are in use until the
+    //    aggregate) stays behind the period's last store as a batch of exactly XFWD_NLD instructions, every one unconditional, and
+    //    the drain waits with vmcnt(XFWD_NLD): everything older — the stores, and the unit batch — has completed, the own-row batch
+    //    stays in flight through the publish, the next poll and the next state loads (tests/test_isa_hazards.py counts the
+    //    instructions between the two markers in the ISA against the immediate).
     constexpr int DPI = D == 0 ? 0 : (D <= 2 ? 1 : D / 2);                 // load instructions per row of policy partials
-    constexpr int XFWD_NLD = 2 * (1 + (VAL ? (D > 0 ? 2 : 1) : 1 + (D > 0 ? 1 : 0)) + DPI) + (1 + DPI + (VAL ? 2 : (D > 0 ? 1 : 0))) + 2;
-    auto next_period_loads = [&](int t) {               // t: the period that has just been stored (ud holds the NEXT period's units by now)
+    constexpr int XFWD_NLD = 1 + DPI + (VAL ? 2 : (D > 0 ? 1 : 0));
+    auto next_units_loads = [&](int t) {                // t: the period being processed (ud holds the NEXT period's units by now)
         const int t1 = min(t + 1, P - 1);
         load_rec(I0, t1, ud[0], 0);
         load_rec(I1, t1, ud[1], 0);
-        prefetch(t1);
         request_units(t + 2);
+    };
+    auto next_period_loads = [&](int t) {               // t: the period that has just been stored
+        prefetch(min(t + 1, P - 1));
     };
     xbar_arrive(!syncw);                                // the initial state has reached L2: episode 1
     if (sync_duty) xpublish(A.sy, x, cW, 1u);
@@ -1312,6 +1327,35 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     bool vnz = false;                                   // the virtual rows may hold mass: some column was clamped last period
     const int son = (x == 0 && cW < 32) ? cW : -1;     // dev stamps (make stamp)
     (void)son;
+    // the aggregate of period tp from the lanes' terms (sync wave; fixed order: columns ascending, then the lanes' DPP tree)
+    auto reduce_agg = [&](int tp) {
+        const double *ap = aggsh + ((size_t)(tp & 1) * ne * 64 + lane) * NAP;
+        double sk[NAP];
+#pragma unroll
+        for (int k = 0; k < NAP; k++) sk[k] = 0.0;
+        for (int k2 = 0; k2 < ne; k2++) {
+            double v[NAP];
+            if (NAP == 1) v[0] = ap[(size_t)k2 * 64 * NAP];
+            else {
+#pragma unroll
+                for (int q = 0; q < NAP / 2; q++) { const double2 d = reinterpret_cast<const double2 *>(ap + (size_t)k2 * 64 * NAP)[q]; v[2 * q] = d.x; v[2 * q + 1] = d.y; }
+            }
+#pragma unroll
+            for (int k = 0; k < NAP; k++) sk[k] += v[k];
+        }
+        const size_t pb = (size_t)tp * Sact + cW;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const double pd = xwave_reduce63(sk[k]);
+            if (lane == 63) A.daggpart[pb * (size_t)(XG * D) + x * D + k] = pd;
+        }
+        if constexpr (VAL) {
+            if (recD) {
+                const double pD = xwave_reduce63(sk[IV]);
+                if (lane == 63) A.aggpart[pb] = pD;
+            }
+        }
+    };
     for (int t = 0; t < P; t++) {
         XSTAMP(1, son, t, 0);
         const size_t base = (size_t)t * G + (size_t)e * na;
@@ -1328,6 +1372,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         if (sync_duty) xpoll(A.sy, x, sw & 255, (sw >> 8) & 255, (unsigned)(t + 1));   // this period's source members have published period t-1
         xlds_barrier();
         XSTAMP(1, son, t, 1);
+        if (sync_duty && t > 0) reduce_agg(t - 1);      // (the sync wave has nothing else to do until the gathers are done)
         double pagg[DD];
 #pragma unroll
         for (int k = 0; k < DD; k++) pagg[k] = 0.0;
@@ -1342,6 +1387,9 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
             // Young lottery of a source (ForwardIteration.jl:59-73): (1-w) to row lo, w to row lo+1; the weight's partial is
             // dpol / gap (zero where clamped), times D_{t-1} of the row. Only the parts that land in the unit's own target run
             // [ta, tb) are added (the other part of a seam source belongs to the neighbouring unit).
+#ifdef HANK_DEV_NOATOMIC      // timing experiment only (wrong numbers): what the same-address serialisation of the LDS adds costs
+#define lds_add(p, v) (*(p) = (v))
+#endif
             auto process = [&](auto U, int2 d) {
                 constexpr int u = decltype(U)::value;
                 if (!qon[u]) return;
@@ -1373,6 +1421,9 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
             };
             process(I0, ud[0]);
             process(I1, ud[1]);
+#ifdef HANK_DEV_NOATOMIC
+#undef lds_add
+#endif
             // (rare) a unit wider than a wave — more than 64 sources on ONE target row — and units beyond the member's 2 n_e slots
             const int nu = (sw >> 18) & 0xff;
             for (int u2 = wv; u2 < nu; u2 += ne) {
@@ -1407,17 +1458,20 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         vnz = ((sw >> 16) & 1) != 0;
         const int nxt = cur ^ 1;
         if (!syncw) {
+            next_units_loads(t);                        // accepted by the memory path while the waves mix (see above)
             // exogenous transition: D_t[., e] = sum_k D_mid[., k] Pi[k, e] (ForwardIteration.jl:95-99), value and partials in one pass
             double mx[NSL];
-            if (PIREG) xtile_mix_reg<SL, NSL>(tile + (size_t)lane * SL, pr, ne, mx);
-            else xtile_mix<SL, NSL>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
+            if (PIREG) xtile_mix_reg<SL, NSL, true>(tile + (size_t)lane * SL, pr, ne, mx);
+            else xtile_mix<SL, NSL, true>(tile + (size_t)lane * SL, Pish + ne * e, 1, ne, mx);
             if (live) {
                 double sv[SP];
 #pragma unroll
                 for (int k = 0; k < SP; k++) sv[k] = k < NSL ? mx[k] : 0.0;
                 rows.store((size_t)nxt * hs + slot, sv);
             }
-            const size_t pb = (size_t)t * Sact * ne + (size_t)cW * ne + e;
+            double at[NAP];
+#pragma unroll
+            for (int k = 0; k < NAP; k++) at[k] = 0.0;
             if constexpr (VAL) {
                 if (recL && own) {
                     // what the tangent sweeps read per SOURCE: {w, ig * D_{t-1}} (k_lottery's w and ig)
@@ -1429,8 +1483,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
                     if (own) R.Dseq[(size_t)(t + 1) * G + pt] = mx[IV];
                     else if (virt) A.Dvirt[((size_t)t * ne + e) * 64 + cW] = mx[IV];
                     // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307); a virtual row carries row 0's policy
-                    const double pD = xwave_reduce63(live ? polr * mx[IV] : 0.0);
-                    if (lane == 63) A.aggpart[pb] = pD;
+                    at[IV] = live ? polr * mx[IV] : 0.0;
                 }
             }
             // aggregate partials: pol_t dD_t + dpol_t D_t. Value carried: a row's own policy partials meet its new D_t here (a
@@ -1441,9 +1494,9 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
                 double term = live ? polr * mx[k] : 0.0;
                 if constexpr (VAL) term = live ? (polr * mx[k] + dpr[k] * mx[IV]) : 0.0;
                 else term = (term + pagg[k]) + ((own && r < clo) ? dpr[k] * Dr : 0.0);
-                const double pd = xwave_reduce63(term);
-                if (lane == 63) A.daggpart[pb * (size_t)(XG * D) + x * D + k] = pd;
+                at[k] = term;
             }
+            xtile_store<NAP>(aggsh + (((size_t)(t & 1) * ne + e) * 64 + lane) * NAP, at);      // summed by the sync wave in the next period (reduce_agg)
 #pragma unroll
             for (int k = 0; k < NSL; k++) mxp[k] = mx[k];
         }
@@ -1452,12 +1505,15 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         if (!syncw) {
             asm volatile("; XFWD_BATCH_BEGIN" ::: "memory");
             next_period_loads(t);
+            XSTAMP(1, son, t, 7);
             asm volatile("; XFWD_BATCH_END\n\ts_waitcnt vmcnt(%0)" ::"n"(XFWD_NLD) : "memory");       // this member's stores have reached L2 ...
+            XSTAMP(1, son, t, 8);
         }
         xlds_barrier();
         if (sync_duty) xpublish(A.sy, x, cW, (unsigned)(t + 2));                                       // ... episode t+2
         XSTAMP(1, son, t, 6);
     }
+    if (sync_duty) reduce_agg(P - 1);                   // (every wave wrote its terms before the last barrier)
 }
 
 // the forward sweeps' work units from the lottery record (see k_xfwd), one block per (period, member): thread e cuts column

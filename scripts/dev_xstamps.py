@@ -42,12 +42,13 @@ wv = raw[2 * NM * 8 * 12:].reshape(2, NM, 8, 16)
 tm = hb.last_timings()
 sweep_ms = {0: tm["primal_backward" if DUAL else "tangent_backward"]["ms"], 1: tm["tangent_forward"]["ms"]}
 names = {0: ["top", "search done", "Y issued", "tile barrier", "X issued", "arrived"] if DUAL else ["top", "srcpoll+BA", "Y issued", "allpoll+BB", "X issued", "arrived"],
-         1: ["top", "srcpoll+BA", "gathered", "tile done", "allpoll+BB", "C issued", "published"]}
+         1: ["top", "srcpoll+BA", "gathered", "tile done", "allpoll+BB", "C issued", "batch issd", "stores ackd", "published"]}
+order = {0: None, 1: [0, 1, 2, 3, 4, 5, 7, 8, 6]}        # the forward sweep's stamps in time order (7, 8 were added between 5 and 6)
 # s_memrealtime: one 100 MHz counter for the whole chip (10 ns per tick): every member of group 0 on one clock.
 # Per member: median over the stamped periods of (stamp - earliest top of any member in that period), in ns
 for sw, sname in ((0, "backward"), (1, "forward")):
     ns = len(names[sw])
-    s_ = st[sw][:, :, :ns].astype(float) * 10.0            # [member][period][stamp]
+    s_ = (st[sw][:, :, :ns] if order[sw] is None else st[sw][:, :, order[sw]]).astype(float) * 10.0            # [member][period][stamp]
     live = (st[sw][:, :, 0] != 0).all(axis=1)
     t0 = s_[live][:, :, 0].min(axis=0)                      # earliest top per period
     per = np.median(np.diff(s_[live][:, :, 0], axis=1))
@@ -65,8 +66,8 @@ for sw, sname in ((0, "backward"), (1, "forward")):
         print(f"   {mbr:6d} " + " ".join(f"{v:11.0f}" for v in rel) + "   | " + " ".join(f"{v:5.0f}" for v in np.diff(rel)))
 
 # every wave's arrival at the chosen point of the period (backward: the tile barrier of the Y half), ns after the member's top
-for sw, sname in ((0, "backward"),):
-    for mbr in (0, 8, 16, 24, 31):
+for sw, sname in ((0, "backward"), (1, "forward")):
+    for mbr in ((0, 8, 16, 24, 31) if sw == 0 else (0, 4, 8, 9, 10, 11, 12, 14, 20, 31)):
         if (st[sw][mbr, :, 0] == 0).any():
             continue
         rel = np.median(wv[sw][mbr].astype(float) * 10.0 - st[sw][mbr, :, 0:1].astype(float) * 10.0, axis=0)
