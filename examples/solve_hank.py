@@ -20,21 +20,24 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def build(n_a=1000, n_e=7, T=500):
+def build(n_a=1000, n_e=7, T=500, spec="one_asset_hank.yaml"):
+    """spec: one_asset_hank.yaml (asset-market clearing, one heterogeneous variable) or one_asset_hank_goods.yaml (goods-market
+    clearing: savings AND consumption aggregated by the device sweeps)."""
     import hank_amd as h
     from hank_amd import OneAssetHANK as oa
     ov = {"T": T, "dimensions": {"wealth": {"n": n_a}, "productivity": {"n": n_e}}}
-    m = h.build_model_from_yaml(str(ROOT / "examples" / "one_asset_hank.yaml"), overrides=ov)
+    m = h.build_model_from_yaml(str(ROOT / "examples" / spec), overrides=ov)
     m.params.B = oa.calibrate_bond_supply(m)
     ss, _ = h.get_SteadyStates(m)
     return m, ss
 
 
-def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False, inner="fixed_point", jacobian="toeplitz"):
+def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False, inner="fixed_point", jacobian="toeplitz",
+          spec="one_asset_hank.yaml"):
     import hank_amd as h
     import hank_amd.parallel  # noqa: F401  (pulls in torch before the clock starts)
     t0 = time.perf_counter()
-    m, ss = build(n_a, n_e, T)
+    m, ss = build(n_a, n_e, T, spec)
     t_ss = time.perf_counter() - t0
     P = T - 1
     ei = shock * rho ** np.arange(P)
@@ -50,7 +53,7 @@ def solve(n_a=1000, n_e=7, T=500, shock=0.0025, rho=0.6, eps=1e-9, verbose=False
     t_newton = time.perf_counter() - t0
     lin = h.LinearizedFunction(x, {"ei": ei}, m, ss, ss)
     X = x.reshape(len(keys), P, order="F")
-    out = {"model": "one-asset HANK", "grid": f"{n_a}x{n_e}", "T": T, "shock": f"ei_t = {shock}*{rho}^(t-1)",
+    out = {"model": "one-asset HANK", "spec": spec, "grid": f"{n_a}x{n_e}", "T": T, "shock": f"ei_t = {shock}*{rho}^(t-1)",
            "B": m.params.B, "calibrate_and_steady_state_s": round(t_ss, 3), "ss_jacobian_s": round(t_jac, 3),
            "newton_s": round(t_newton, 3), "preconditioner_setup_s": round(h.y_Iteration.setup_s, 3),      # (inside newton_s: J̅⁻¹ on the device, once per J̅)
            "newton_iterations": h.NewtonRaphsonHANK.iterations,
@@ -69,6 +72,7 @@ if __name__ == "__main__":
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--inner", default="fixed_point", choices=["fixed_point", "krylov"])
     ap.add_argument("--jacobian", default="toeplitz", choices=["toeplitz", "columns"])
+    ap.add_argument("--spec", default="one_asset_hank.yaml", choices=["one_asset_hank.yaml", "one_asset_hank_goods.yaml"])
     a = ap.parse_args()
     import os
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -78,7 +82,7 @@ if __name__ == "__main__":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
-    out = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose and rank == 0, inner=a.inner, jacobian=a.jacobian)[0]
+    out = solve(a.n_a, a.n_e, a.T, a.shock, verbose=a.verbose and rank == 0, inner=a.inner, jacobian=a.jacobian, spec=a.spec)[0]
     out["n_gpus"] = world
     if rank == 0:
         print(json.dumps(out))

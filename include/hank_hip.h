@@ -154,6 +154,26 @@ int hank_primal_jvp_dev(hank_ctx *ctx, const double *d_xhh, const double *d_dxhh
  * out[(G, P, N)] column-major (seqs_data[j][t] as Matrix{Dual}). */
 int hank_get_policy_seq(hank_ctx *ctx, double *out);
 int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out);
+/* More than one heterogeneous variable. BackwardIteration keeps one policy sequence per heterogeneous variable
+ * (`seqs_data[j][t] = result[varname]`, BackwardIteration.jl:99-112) and ForwardIteration aggregates every one of them with the
+ * SAME D_t: `agg_data[j][t] = dot(vec(policy_seqs[varname][t]), D)` (ForwardIteration.jl:303-307). Every forward kernel of the
+ * fused sweeps (k_dist_step, k_tan_fwd / k_fused_fwd, k_xfwd, k_wide_fwd) therefore reduces TWO dot products per period with the
+ * D_t / dD_t it holds: the policy-weighted one (hank_primal / hank_jvp's output) and the grid-weighted one, sum_pt a(pt) D_t(pt).
+ * Any policy that is affine in (a, z_e, 1, a') with coefficients that depend on the period's inputs aggregates as the same
+ * affine combination of them; the budget residual c = (1+r_t) a + w_t z_e + tr_t - a' (the c_grid of KrusellSmith.jl:79) is the
+ * one built in:
+ *   hank_get_het_outputs(ctx, n_het, dxhh, N, agg_out, dagg_out): output 0 = the policy variable of the endogenous dimension
+ *   (KD / A: what hank_primal and hank_jvp return), output 1 = consumption; n_het in {1, 2} says how many the model's
+ *   `heterogeneous:` section lists. agg_out (P, n_het) column-major of the last primal sweep; dagg_out (P, n_het, N)
+ *   column-major of the last tangent sweep — whichever kernel family ran it — whose input `dxhh` (n_hh, P, N) is passed
+ *   again (the partials of r_t, w_t, tr_t enter consumption directly). dagg_out NULL or N = 0: values only.
+ *   hank_get_grid_aggregates: the raw second reduction, agg2_out[P] = sum a D_t and dagg2_out (P, N) = sum a dD_t, for a host
+ *   that assembles other affine outputs itself.
+ * The _dev forms take device pointers and are ordered on the context's stream.                                              */
+int hank_get_het_outputs(hank_ctx *ctx, int32_t n_het, const double *dxhh, int32_t N, double *agg_out, double *dagg_out);
+int hank_get_het_outputs_dev(hank_ctx *ctx, int32_t n_het, const double *d_dxhh, int32_t N, double *d_agg_out, double *d_dagg_out);
+int hank_get_grid_aggregates(hank_ctx *ctx, double *agg2_out, int32_t N, double *dagg2_out);
+int hank_get_grid_aggregates_dev(hank_ctx *ctx, double *d_agg2_out, int32_t N, double *d_dagg2_out);
 /* The distribution path D_1..D_P of the last hank_primal -> out[P*G] (ForwardIteration.jl:297-300). */
 int hank_get_dist_seq(hank_ctx *ctx, double *out);
 

@@ -55,6 +55,12 @@ def household_inputs(xVec_endog, exog_paths, model: SequenceModel):
     return xhh, dxhh
 
 
+def policy_variable(model: SequenceModel) -> str:
+    """the heterogeneous variable that moves the distribution: the endogenous dimension's `policy_var`
+    (ForwardIteration.jl:297-300)."""
+    return next(d.policy_var for d in model.heterogeneity.values() if d.dim_type == "endogenous")
+
+
 class PolicySequences(dict):
     """BackwardIteration's return value: {het_var: list of P (n_a x n_e) matrices}; the matrices are
     fetched from HBM lazily. Carries the tag ForwardIteration uses to stay on the fused path.
@@ -64,9 +70,10 @@ class PolicySequences(dict):
     (one sweep in all, NewtonRaphson.jl:78-79) or until a policy matrix is actually read (then the sweep runs
     with a placeholder D_0; policies do not depend on it)."""
 
-    def __init__(self, hb, het_keys, is_dual, N, pending):
+    def __init__(self, hb, het_keys, is_dual, N, pending, model=None):
         super().__init__()
         self._hb, self._het_keys, self._is_dual, self._N = hb, het_keys, is_dual, N
+        self._model = model                # (a second heterogeneous variable is derived from the policy variable: _fetch)
         self._pending = pending            # {"xhh", "dxhh", "value"} until the device sweep has run
         self._D_used, self._generation = None, None
         self._fetched = False
@@ -83,6 +90,8 @@ class PolicySequences(dict):
             agg, dagg = hb.primal(pend["xhh"]), None
         hb._generation = getattr(hb, "_generation", 0) + 1
         hb._last = {"agg": agg, "dagg": dagg, "D0": D0, "xhh": pend["xhh"], "dxhh": pend["dxhh"], "value": pend["value"]}
+        if len(self._het_keys) > 1:        # every heterogeneous variable's aggregate, reduced by the same sweeps
+            hb._last["het"] = hb.het_outputs(len(self._model.value_fn.outputs), pend["dxhh"])
         self._D_used, self._generation, self._pending = D0, hb._generation, None
 
     def _fetch(self):
@@ -99,8 +108,20 @@ class PolicySequences(dict):
             seq = [Dual(pol[:, :, t], dpol[:, :, t, :]) for t in range(hb.P)]
         else:
             seq = [pol[:, :, t] for t in range(hb.P)]
+        pol_key = self._het_keys[0] if self._model is None else policy_variable(self._model)
         for k in self._het_keys:
-            dict.__setitem__(self, k, seq)
+            if k == pol_key:
+                dict.__setitem__(self, k, seq)
+                continue
+            # another heterogeneous variable: the plugin derives it from the policy variable and the period's inputs (the
+            # reference's value_fn returns it next to the policy, BackwardIteration.jl:108-111)
+            vf, last = self._model.value_fn, hb._last
+            other = []
+            for t in range(hb.P):
+                xv = {name: (Dual(last["xhh"][j, t], last["dxhh"][j, t, :]) if self._is_dual else last["xhh"][j, t])
+                      for j, name in enumerate(vf.household_inputs)}
+                other.append(vf.derived_policy(k, seq[t], xv, self._model))
+            dict.__setitem__(self, k, other)
         self._fetched = True
 
     def __getitem__(self, k):
@@ -137,7 +158,7 @@ def BackwardIteration(xVec_endog, exog_paths, model: SequenceModel, ss_end, ss_i
         from .hip import DomainError, HANK_ERR_DOMAIN
         raise DomainError(HANK_ERR_DOMAIN, f"1 + r must be positive (period {bad})")
     seqs = PolicySequences(hb, het_keys, dxhh is not None, 0 if dxhh is None else dxhh.shape[2],
-                           {"xhh": xhh, "dxhh": dxhh, "value": np.array(ss_end.value, dtype=np.float64, copy=True)})
+                           {"xhh": xhh, "dxhh": dxhh, "value": np.array(ss_end.value, dtype=np.float64, copy=True)}, model)
     if ss_initial is not None:
         seqs._run(np.asarray(ss_initial.D, dtype=np.float64))
     return seqs

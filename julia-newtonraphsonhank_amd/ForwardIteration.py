@@ -62,13 +62,14 @@ def ForwardIteration(policy_seqs, model: SequenceModel, ss_initial):
     D0 = np.asarray(ss_initial.D, dtype=np.float64)
 
     pol_key = endog[0][1].policy_var
-    if isinstance(policy_seqs, PolicySequences) and policy_seqs._pending is not None and tuple(het_keys) == (pol_key,):
+    outs = tuple(model.value_fn.outputs)
+    fused = pol_key in het_keys and all(k in outs for k in het_keys)     # (the variables the device sweeps reduce: hank_get_het_outputs)
+    if isinstance(policy_seqs, PolicySequences) and policy_seqs._pending is not None and fused:
         policy_seqs._run(D0)         # the deferred sweep of a 4-argument BackwardIteration: ONE pass, with the right D_0
     if isinstance(policy_seqs, PolicySequences) and getattr(hb, "_generation", None) == policy_seqs._generation \
-            and tuple(het_keys) == (pol_key,) and getattr(hb, "_last", None) is not None:
-        # fused path: the device sweep aggregates the policy variable with its own policy; a family with a second
-        # heterogeneous variable must take the generic path below (ForwardIteration.jl:303-305 aggregates each
-        # variable with ITS policy)
+            and fused and getattr(hb, "_last", None) is not None:
+        # fused path: the device sweeps aggregate every heterogeneous variable of the family with the D_t they hold
+        # (ForwardIteration.jl:303-307: each variable with ITS policy, all with the same D_t)
         last = hb._last
         if not np.array_equal(last["D0"], D0):
             # the backward sweep did not know ss_initial: redo the fused sweep with the right D_0
@@ -76,9 +77,14 @@ def ForwardIteration(policy_seqs, model: SequenceModel, ss_initial):
             agg = hb.primal(last["xhh"])
             dagg = hb.jvp(last["dxhh"]) if last["dxhh"] is not None else None
             last.update(agg=agg, dagg=dagg, D0=D0)
+            if "het" in last:
+                last["het"] = hb.het_outputs(len(outs), last["dxhh"])
         agg, dagg = last["agg"], last["dagg"]
-        out = Dual(agg, dagg) if dagg is not None else agg
-        return {k: out for k in het_keys}
+        if len(het_keys) == 1:
+            return {pol_key: Dual(agg, dagg) if dagg is not None else agg}
+        aggs, daggs = last["het"]
+        return {k: (Dual(aggs[:, outs.index(k)].copy(), np.ascontiguousarray(daggs[:, outs.index(k), :])) if daggs is not None
+                    else aggs[:, outs.index(k)].copy()) for k in het_keys}
 
     # generic path: explicit policy matrices, one granular device step per period
     seqs = {k: policy_seqs[k] for k in het_keys}

@@ -33,8 +33,17 @@ class _KSValueFunction:
     name = "ValueFunction"
     value_fn_id = HANK_VF_KRUSELL_SMITH
     household_inputs = ("r", "w")   # rows of xVals the household block reads
-    outputs = ("KD",)               # one policy per heterogeneous variable
+    outputs = ("KD", "C")           # one policy per heterogeneous variable a model may list: the reference's KD, and consumption (the
+                                    # c_grid of KrusellSmith.jl:79 as a second policy: hank_get_het_outputs; not returned by the reference's plugin)
     endogenous_dim, exogenous_dim = "wealth", "productivity"
+
+    def derived_policy(self, key: str, policy, xVals: dict, model):
+        """a heterogeneous variable other than the policy variable from the savings policy (n_a, n_e), Float64 or `Dual`."""
+        if key != "C":
+            raise KeyError(key)
+        grid = model.heterogeneity["wealth"].grid
+        z = model.heterogeneity["productivity"].grid
+        return (1.0 + xVals["r"]) * grid[:, None] + xVals["w"] * z[None, :] - policy
 
     def host_steady_state_step(self, value_next: np.ndarray, xVals: dict, model) -> dict:
         """one Float64 EGM step for the host steady-state VFI (same algebra as KrusellSmith.jl:59-80)."""
@@ -52,7 +61,7 @@ class _KSValueFunction:
             g[:, e] = np.interp(grid, s[:, e], grid)   # flat outside [s_1, s_n]
         g = np.maximum(g, bc)
         c = (1.0 + r) * grid[:, None] + w * z[None, :] - g
-        return {"Value": (1.0 + r) * c ** (-γ), "KD": g}
+        return {"Value": (1.0 + r) * c ** (-γ), "KD": g, "C": c}
 
     def __call__(self, *a, **k):
         raise RuntimeError("ValueFunction is a native kernel family (libhank_hip); on the transition "

@@ -44,10 +44,13 @@ class LinearizedFunction:
         self.hb = household_block(mod)
         xhh, _ = household_inputs(self.x, exog_paths, mod)
         self._xhh = xhh
-        self._record_primal()
         het = vars_of_type(mod, "heterogeneous")
         self.het = het
-        self._xMat = assemble_full_xMat(self.x, {k: self.agg for k in het}, exog_paths, mod, ss_initial, ss_ending)
+        outs = tuple(mod.value_fn.outputs)
+        self._out_idx = [outs.index(k) for k in het]        # device output of each heterogeneous variable (hank_get_het_outputs)
+        self._n_out = len(outs) if len(het) > 1 else 1
+        self._record_primal()
+        self._xMat = assemble_full_xMat(self.x, {k: self.aggs[:, j] for k, j in zip(het, self._out_idx)}, exog_paths, mod, ss_initial, ss_ending)
         self.Fx = Residuals(self._xMat, mod)
         self._Rx = self._Ragg = None        # the residual layer's linearisation at this x, built at the first jvp
 
@@ -104,6 +107,7 @@ class LinearizedFunction:
         hb = self.hb
         hb.set_boundary(self.ss_ending.value, self.ss_initial.D)
         self.agg = hb.primal(self._xhh)
+        self.aggs = self.agg[:, None] if self._n_out == 1 else hb.het_outputs(self._n_out)[0]      # (P, outputs)
         hb._generation = getattr(hb, "_generation", 0) + 1
         hb._last = None          # an older PolicySequences must not take ForwardIteration's fused shortcut
         self._generation = hb._generation
@@ -122,6 +126,7 @@ class LinearizedFunction:
         N = dxhh.shape[2]
         nz = np.flatnonzero(np.any(dxhh != 0.0, axis=(0, 1)))
         dagg = np.zeros((dxhh.shape[1], N))
+        daggs = dagg[:, None, :] if self._n_out == 1 else np.zeros((dxhh.shape[1], self._n_out, N))      # (P, outputs, N)
         if len(nz):
             if getattr(self.hb, "_generation", None) != self._generation:
                 # another linearisation / BackwardIteration used the model's context since: its record is not
@@ -134,14 +139,16 @@ class LinearizedFunction:
                 padded[:, :, :len(nz)] = sub
                 sub = padded
             dagg[:, nz] = self.hb.jvp(sub)[:, :len(nz)]
+            if self._n_out > 1:
+                daggs[:, :, nz] = self.hb.het_outputs(self._n_out, sub)[1][:, :, :len(nz)]
         if self.exact_residual_layer:           # the reference's way: re-evaluate the equations under the Dual every time
-            agg = {k: Dual(self.agg, dagg) for k in self.het}
+            agg = {k: Dual(self.aggs[:, j], np.ascontiguousarray(daggs[:, j, :])) for k, j in zip(self.het, self._out_idx)}
             res = Residuals(assemble_full_xMat(xd, agg, self.exog_paths, self.mod, self.ss_initial, self.ss_ending), self.mod)
             return res.p[:, 0].copy() if single else res.p.copy()
         if self._Rx is None:
             self._linearise_residuals()
         Y = y[:, None] if single else y
-        out = self._Rx @ Y + self._Ragg @ np.tile(dagg, (len(self.het), 1))     # (one heterogeneous variable per household block: every het row sees the block's aggregate)
+        out = self._Rx @ Y + self._Ragg @ np.concatenate([daggs[:, j, :] for j in self._out_idx], axis=0)     # rows: het variable, period
         return out[:, 0].copy() if single else out
 
 

@@ -12,8 +12,12 @@ Household: CRRA consumption-savings with idiosyncratic productivity z_e, one ass
 where om_t is after-tax labour income per efficiency unit (hours are demand-determined and rationed equally) and
 Tr_t a lump-sum transfer (dividends + net government transfers). This is the Krusell-Smith EGM step
 (KrusellSmith.jl:59-80) with a lump sum added to cash on hand, so the native kernel family
-HANK_VF_ONE_ASSET_HANK reuses egm_X / egm_Y and their tangent forms with a third household input. Consumption
-needs no second aggregate: C_t = (1 + r_t) A_{t-1} + om_t + Tr_t - A_t by the budget identity (sum z_e D = 1).
+HANK_VF_ONE_ASSET_HANK reuses egm_X / egm_Y and their tangent forms with a third household input.
+
+TWO heterogeneous variables: the savings policy `A` and consumption `C` (the budget residual, the c_grid of
+KrusellSmith.jl:79 returned as a second policy). A model lists the ones its equations use under `heterogeneous:`;
+ForwardIteration aggregates each with the same D_t (ForwardIteration.jl:303-307) — on the device, inside the fused
+sweeps (hank_get_het_outputs).
 """
 from __future__ import annotations
 
@@ -33,8 +37,17 @@ class _HANKValueFunction:
     name = "HANKValueFunction"
     value_fn_id = HANK_VF_ONE_ASSET_HANK
     household_inputs = ("r", "om", "Tr")   # rows of xVals the household block reads
-    outputs = ("A",)
+    outputs = ("A", "C")                    # device output index = position here (hank_get_het_outputs)
     endogenous_dim, exogenous_dim = "wealth", "productivity"
+
+    def derived_policy(self, key: str, policy, xVals: dict, model):
+        """a heterogeneous variable other than the policy variable, from the savings policy (n_a, n_e) — Float64 or `Dual` —
+        and the period's inputs: consumption, the budget residual."""
+        if key != "C":
+            raise KeyError(key)
+        grid = model.heterogeneity["wealth"].grid
+        z = model.heterogeneity["productivity"].grid
+        return (1.0 + xVals["r"]) * grid[:, None] + (xVals["om"] * z[None, :] + xVals["Tr"]) - policy
 
     def host_steady_state_step(self, value_next: np.ndarray, xVals: dict, model) -> dict:
         """one Float64 EGM step for the host steady-state VFI (the KS step with the transfer in cash on hand)."""
@@ -53,7 +66,7 @@ class _HANKValueFunction:
             g[:, e] = np.interp(grid, s[:, e], grid)   # flat outside [s_1, s_n]
         g = np.maximum(g, bc)
         c = (1.0 + r) * grid[:, None] + inc - g
-        return {"Value": (1.0 + r) * c ** (-γ), "A": g}
+        return {"Value": (1.0 + r) * c ** (-γ), "A": g, "C": c}
 
     def __call__(self, *a, **k):
         raise RuntimeError("HANKValueFunction is a native kernel family (libhank_hip); on the transition path it is "

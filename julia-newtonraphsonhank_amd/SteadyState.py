@@ -98,6 +98,9 @@ class SSAssembler:
                 raise ValueError(str(e)) from e
             self.vfi_steps += steps
             res = {"Value": v, self.endog_dim.policy_var: pol}
+            for k in vars_of_type(model, "heterogeneous"):
+                if k not in res:
+                    res[k] = vf.derived_policy(k, pol, xv, model)
         else:
             res = vf.host_steady_state_step(value, xv, model)
             for _ in range(10_000):
@@ -184,6 +187,9 @@ def find_ss(model: SequenceModel, ss_spec, label: str, verbose: bool = False, vf
         from .BackwardIteration import household_block
         _, pol = household_block(model).backward_step(ss_value, [vars_[k] for k in model.value_fn.household_inputs])
         res = {asm.endog_dim.policy_var: pol}
+        for k in vars_of_type(model, "heterogeneous"):
+            if k not in res:
+                res[k] = model.value_fn.derived_policy(k, pol, vars_, model)
     else:
         res = model.value_fn.host_steady_state_step(ss_value, vars_, model)
     het_keys = vars_of_type(model, "heterogeneous")

@@ -85,6 +85,10 @@ def getSteadyStateJacobian(ss, model: SequenceModel, chunk: int = 512, drop_tol:
     x_ss = np.tile(np.array([ss.vars[k] for k in endog_keys]), P)
     exog_ss = {k: np.full(P, float(ss.vars[k])) for k in exog_keys}
     lin = LinearizedFunction(x_ss, exog_ss, model, ss, ss)
+    if method == "toeplitz" and len(lin.het) > 1:
+        # hank_fake_news carries the expectation vectors of the policy variable's aggregate only: a model with a second
+        # heterogeneous variable takes the unit-tangent columns (exact at any path; n JVPs in device batches)
+        method = "columns"
     if method == "toeplitz":
         from .GeneralStructures import var_names
         keys = var_names(model)

@@ -108,7 +108,9 @@ struct hank_ctx {
     int T = 0;
     double *d_a = nullptr, *d_z = nullptr, *d_Pi = nullptr;
     double *d_ss_value = nullptr, *d_ss_D = nullptr;  // d_ss_D aliases Dseq[0]
-    double *d_xhh = nullptr, *d_agg = nullptr, *d_aggpart = nullptr;
+    double *d_xhh = nullptr, *d_agg = nullptr, *d_aggpart = nullptr;     // d_agg: (P, 2) column-major — the policy-weighted aggregate, then the grid-weighted one
+    double *d_agg_rm = nullptr;     // [P][2] as the reduction leaves it
+    double *d_zd = nullptr;         // [2][P]: sum_e z_e m_t(e) and sum_e m_t(e), m_t = Pi' m_{t-1} the productivity marginal of D_t (hank_get_het_outputs)
     int *d_err = nullptr;
     int nbp = 0;  // row blocks of the primal kernels
     bool boundary_set = false, primal_done = false;
@@ -262,7 +264,8 @@ static int build_primal_graphs(hank_ctx *ctx) {
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     for (int t = 0; t < P; t++)
         hipLaunchKernelGGL(k_dist_step, grd, blk, lds, s, c, ctx->R, t, ctx->d_aggpart);
-    hipLaunchKernelGGL(k_reduce_parts, dim3(P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
+    hipLaunchKernelGGL(k_reduce_parts, dim3(P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 2, ctx->d_agg_rm);
+    hipLaunchKernelGGL(k_tan_out, dim3((2 * P + 255) / 256), dim3(256), 0, s, ctx->d_agg_rm, P, 2, ctx->d_agg);
     rc = end_capture(ctx, &ctx->g_pfwd);
     ctx->launches[0] = P + 2;
     ctx->launches[1] = P + 1;
@@ -334,8 +337,8 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int which) {
         LAUNCH_RG_SS(RGF, w.gf.ss, k_tan_fwd, VF, dim3(nbf, nyf), blk, 0, s, c, ctx->R, w.gf, t, dD[cur], dD[cur ^ 1], dpolf, aggpart);
         cur ^= 1;
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
-    hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (2 * N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, 2 * N, w.dagg);
+    hipLaunchKernelGGL(k_tan_out, dim3((2 * PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, 2 * N, w.dagg_cm);
     rc = end_capture(ctx, &w.g_fwd);
     if (rc) return rc;
     ctx->launches[2] = (int)P + 2;
@@ -377,9 +380,10 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int which) {
                   dD[cur], dD[cur ^ 1], dpolf, aggpart);
         if (tt >= 0) cur ^= 1;
     }
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 1, ctx->d_agg);
-    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, N, w.dagg);
-    hipLaunchKernelGGL(k_tan_out, dim3((PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, N, w.dagg_cm);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, ctx->d_aggpart, ctx->nbp, 2, ctx->d_agg_rm);
+    hipLaunchKernelGGL(k_tan_out, dim3((unsigned)((2 * P + 255) / 256)), dim3(256), 0, s, ctx->d_agg_rm, (int)P, 2, ctx->d_agg);
+    hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (2 * N + 63) / 64), dim3(256), 0, s, w.aggpart, (int)nbf, 2 * N, w.dagg);
+    hipLaunchKernelGGL(k_tan_out, dim3((2 * PN + 255) / 256), dim3(256), 0, s, w.dagg, (int)P, 2 * N, w.dagg_cm);
     rc = end_capture(ctx, &w.g_ffwd);
     ctx->launches[4] = (int)P + 5;
     ctx->launches[5] = (int)P + 5;
@@ -438,9 +442,9 @@ static int ensure_tanwork(hank_ctx *ctx, int N) {
             HIPC(ctx, dmalloc(&w.dD[k], GV * N));
         }
         HIPC(ctx, dmalloc(&w.dpol, P * G * N));
-        HIPC(ctx, dmalloc(&w.aggpart, P * (size_t)nbf * N));
-        HIPC(ctx, dmalloc(&w.dagg, P * N));
-        HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
+        HIPC(ctx, dmalloc(&w.aggpart, 2 * P * (size_t)nbf * N));      // both aggregates: [P][blocks][2 N]
+        HIPC(ctx, dmalloc(&w.dagg, 2 * P * N));
+        HIPC(ctx, dmalloc(&w.dagg_cm, 2 * P * N));                    // (P, 2 N) column-major: the policy-weighted aggregate's N columns, then the grid-weighted one's
         return HANK_OK;
     };
     const int rc = alloc();
@@ -512,8 +516,8 @@ static size_t x_lds_dual_back(const Consts &c, int D) {
 // k_xfwd with NSL live slots (the D partials + the value): tile, Pi, {source range, clamped prefix} and source members of every period
 static size_t x_lds_fwd(const Consts &c, int NSL) {
     const int SLt = NSL <= 2 ? NSL : (NSL <= 6 ? 6 : 10);      // XSlots<NSL>::SL
-    const int NAP = NSL == 1 ? 1 : ((NSL + 1) / 2) * 2;        // the aggregate's terms per lane (k_xfwd: aggsh)
-    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + 1 + 2 * (size_t)c.n_e * 64 * NAP) + sizeof(int) * ((size_t)c.P * c.n_e + c.P) + 64;
+    const int NAP = 2 * NSL;                                   // the two aggregates' terms per lane (k_xfwd: aggsh)
+    return sizeof(double) * ((size_t)SLt * c.n_e * 64 + (size_t)c.n_e * c.n_e + 1 + (size_t)c.n_e * 64 * NAP) + sizeof(int) * ((size_t)c.P * c.n_e + c.P) + 64;
 }
 // the grid fits the XCD-local schedule: a 63-row slab per CU of an XCD, and the Float64 sweeps' LDS (which holds the
 // per-period inputs of the WHOLE horizon) fits a workgroup
@@ -559,7 +563,7 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.st_D, 2 * XG * std::max(GV, GM)));
     HIPC(ctx, dmalloc(&X.st_dD, 2 * XG * GM * (X.dmax + 2)));      // D partials + the value, padded to pairs
     HIPC(ctx, dmalloc(&X.Dvirt, P * c.n_e * 64));
-    HIPC(ctx, dmalloc(&X.aggpart, P * (size_t)X.Sact * c.n_e));
+    HIPC(ctx, dmalloc(&X.aggpart, 2 * P * (size_t)X.Sact));       // [P][members][2]
     HIPC(ctx, dmalloc(&X.rho, P));
     HIPC(ctx, dmalloc(&X.srcB, P * X.Sact));
     HIPC(ctx, dmalloc(&X.srcF, P * X.Sact));
@@ -626,11 +630,11 @@ static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
         HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
         HIPC(ctx, dmalloc(&w.dxr, P * N)); HIPC(ctx, dmalloc(&w.dxw, P * N)); HIPC(ctx, dmalloc(&w.dxt, P * N));
         HIPC(ctx, dmalloc(&w.dpol, off));
-        const size_t W = (size_t)XG * X.dmax, nb = (size_t)X.Sact * c.n_e;
-        HIPC(ctx, dmalloc(&w.daggpart, P * nb * W));
-        HIPC(ctx, hipMemset(w.daggpart, 0, sizeof(double) * P * nb * W));
-        HIPC(ctx, dmalloc(&w.dagg_pass, P * W));
-        HIPC(ctx, dmalloc(&w.dagg_cm, P * N));
+        const size_t W = (size_t)XG * X.dmax, nb = (size_t)X.Sact;
+        HIPC(ctx, dmalloc(&w.daggpart, 2 * P * nb * W));              // both aggregates: [P][members][2 W]
+        HIPC(ctx, hipMemset(w.daggpart, 0, sizeof(double) * 2 * P * nb * W));
+        HIPC(ctx, dmalloc(&w.dagg_pass, 2 * P * W));
+        HIPC(ctx, dmalloc(&w.dagg_cm, 2 * P * N));                    // (P, 2 N) column-major
         return HANK_OK;
     };
     const int rc = alloc();
@@ -741,7 +745,8 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullp
     }
     HIPC(ctx, hipEventRecord(ctx->ev[2], s));
     if (!skip_fwd) {
-        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact, 1, ctx->d_agg);
+        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact, 2, ctx->d_agg_rm);
+            hipLaunchKernelGGL(k_tan_out, dim3((unsigned)((2 * P + 255) / 256)), dim3(256), 0, s, ctx->d_agg_rm, (int)P, 2, ctx->d_agg);
         hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
     }
     HIPC(ctx, hipGetLastError());
@@ -810,13 +815,15 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_bac
         if (v) { fa.D0 = ctx->d_ss_D; fa.Dvirt = X.Dvirt; fa.aggpart = X.aggpart; }
         x_launch_fwd(X, ps.D, v, grd, blkF, x_lds_fwd(c, ps.D + (v ? 1 : 0)), s, fa);
         if (v) {
-            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact, 1, ctx->d_agg);
+            hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact, 2, ctx->d_agg_rm);
+            hipLaunchKernelGGL(k_tan_out, dim3((unsigned)((2 * P + 255) / 256)), dim3(256), 0, s, ctx->d_agg_rm, (int)P, 2, ctx->d_agg);
             hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
         }
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
         const int W = XG * ps.D;
-        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, W, w->dagg_pass);
-        hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, W, ps.n0, ps.N, w->dagg_cm);
+        hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (2 * W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, 2 * W, w->dagg_pass);
+        hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, 2 * W, 0, ps.n0, ps.N, w->dagg_cm);
+        hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, 2 * W, W, ps.n0, ps.N, w->dagg_cm + P * (size_t)N);
     }
     HIPC(ctx, hipGetLastError());
     rc = x_serialize_end(ctx);
@@ -952,7 +959,7 @@ static int w_ensure_tan(hank_ctx *ctx, int N, bool staging, WTan **out) {
     auto alloc = [&]() -> int {
         if (staging) HIPC(ctx, dmalloc(&w.dxhh, (size_t)c.n_hh * P * N));
         HIPC(ctx, dmalloc(&w.dpol, P * (size_t)N * G + 2));       // (+ 2: the last 16-byte load of an odd-sized grid reads 8 bytes past its row)
-        HIPC(ctx, dmalloc(&w.dagg_cm, P * (size_t)N));
+        HIPC(ctx, dmalloc(&w.dagg_cm, 2 * P * (size_t)N));            // (P, 2 N) column-major: both aggregates
         return HANK_OK;
     };
     const int rc = alloc();
@@ -1108,8 +1115,10 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     ctx->d_ss_D = R.Dseq;
     ctx->nbp = (c.n_a + RBP - 1) / RBP;
     HIPC(ctx, dmalloc(&ctx->d_xhh, (size_t)c.n_hh * P));
-    HIPC(ctx, dmalloc(&ctx->d_agg, P));
-    HIPC(ctx, dmalloc(&ctx->d_aggpart, P * (size_t)ctx->nbp));
+    HIPC(ctx, dmalloc(&ctx->d_agg, 2 * P));
+    HIPC(ctx, dmalloc(&ctx->d_agg_rm, 2 * P));
+    HIPC(ctx, dmalloc(&ctx->d_zd, 2 * P));
+    HIPC(ctx, dmalloc(&ctx->d_aggpart, 2 * P * (size_t)ctx->nbp));
     HIPC(ctx, dmalloc(&ctx->d_err, 4));
     HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
     HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_stream, hipEventDisableTiming));
@@ -1170,7 +1179,7 @@ int hank_destroy(hank_ctx *ctx) {
     ctx->wcur = nullptr;
     (void)hipFree(ctx->rec_slab); (void)hipFree(ctx->d_ibw);
     (void)hipFree(ctx->d_a); (void)hipFree(ctx->d_z); (void)hipFree(ctx->d_Pi); (void)hipFree(ctx->d_ss_value);
-    (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
+    (void)hipFree(ctx->d_xhh); (void)hipFree(ctx->d_agg); (void)hipFree(ctx->d_agg_rm); (void)hipFree(ctx->d_zd); (void)hipFree(ctx->d_aggpart); (void)hipFree(ctx->d_err);
     for (int k = 0; k < 16; k++)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1213,6 +1222,20 @@ int hank_set_boundary(hank_ctx *ctx, const double *ss_end_value, const double *s
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(ctx->d_ss_value, ss_end_value, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
     HIPC(ctx, hipMemcpyAsync(ctx->d_ss_D, ss_init_D, sizeof(double) * G, hipMemcpyHostToDevice, ctx->stream));
+    {   // the productivity marginal of D_t does not depend on the policies (the lottery moves mass within a column, the exogenous
+        // step mixes the columns: ForwardIteration.jl:95-99): m_t = Pi' m_{t-1} from D_0's
+        const int ne = ctx->c.n_e, na = ctx->c.n_a, P = ctx->c.P;
+        std::vector<double> m(ne, 0.0), m2(ne), zd(2 * (size_t)P);
+        for (int e = 0; e < ne; e++) for (int i = 0; i < na; i++) m[e] += ss_init_D[(size_t)e * na + i];
+        for (int t = 0; t < P; t++) {
+            for (int e2 = 0; e2 < ne; e2++) { double v = 0.0; for (int e = 0; e < ne; e++) v += ctx->h_Pi[e + (size_t)ne * e2] * m[e]; m2[e2] = v; }
+            m.swap(m2);
+            double z = 0.0, one = 0.0;
+            for (int e = 0; e < ne; e++) { z += ctx->h_z[e] * m[e]; one += m[e]; }
+            zd[t] = z; zd[(size_t)P + t] = one;
+        }
+        HIPC(ctx, hipMemcpyAsync(ctx->d_zd, zd.data(), sizeof(double) * 2 * P, hipMemcpyHostToDevice, ctx->stream));   // (synchronised below: zd may go)
+    }
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     ctx->boundary_set = true;
     ctx->primal_done = false;
@@ -1761,6 +1784,33 @@ int hank_get_dist_seq(hank_ctx *ctx, double *out) {
     return HANK_OK;
 }
 
+// The grid-weighted aggregate AD_t = sum_pt a(pt) D_t(pt) of the last primal sweep and its N tangents dAD_t = sum a dD_t of the
+// last tangent sweep (whichever family ran it): every forward kernel reduces it next to the policy-weighted one. dev != 0:
+// the outputs are device pointers (copies ordered on the context's stream).
+static int grid_aggregates(hank_ctx *ctx, double *agg2_out, int32_t N, double *dagg2_out, bool dev) {
+    if (!ctx || (!agg2_out && !dagg2_out) || N < 0) return HANK_ERR_BAD_ARG;
+    ENTER(ctx);
+    const size_t P = ctx->c.P;
+    const hipMemcpyKind kind = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (agg2_out) {
+        if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "no primal sweep has been run");
+        HIPC(ctx, join_side(ctx));
+        HIPC(ctx, hipMemcpyAsync(agg2_out, ctx->d_agg + P, sizeof(double) * P, kind, ctx->stream));
+    }
+    if (dagg2_out && N > 0) {
+        const double *src = nullptr;
+        if (ctx->last_tan == 2) { if (ctx->wcur && ctx->wcur->valid && ctx->wcur->N == N) src = ctx->wcur->dagg_cm; }
+        else if (ctx->last_tan == 1) { if (ctx->xcur && ctx->xcur->valid && ctx->xcur->N == N) src = ctx->xcur->dagg_cm; }
+        else if (ctx->tw && ctx->tw->valid && ctx->tw->N == N) src = ctx->tw->dagg_cm;
+        if (!src) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
+        HIPC(ctx, hipMemcpyAsync(dagg2_out, src + P * (size_t)N, sizeof(double) * P * N, kind, ctx->stream));
+    }
+    if (!dev) HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return HANK_OK;
+}
+int hank_get_grid_aggregates(hank_ctx *ctx, double *agg2_out, int32_t N, double *dagg2_out) { return grid_aggregates(ctx, agg2_out, N, dagg2_out, false); }
+int hank_get_grid_aggregates_dev(hank_ctx *ctx, double *d_agg2_out, int32_t N, double *d_dagg2_out) { return grid_aggregates(ctx, d_agg2_out, N, d_dagg2_out, true); }
+
 int hank_get_dpolicy_seq(hank_ctx *ctx, int32_t N, double *out) {
     if (!ctx || !out) return HANK_ERR_BAD_ARG;
     ENTER(ctx);
@@ -1872,6 +1922,84 @@ static int granular_backward(hank_ctx *ctx, const double *value_next, const doub
     HIPC(ctx, hipStreamSynchronize(s));
     ctx->errmsg[0] = 0;
     return HANK_OK;
+}
+
+// ---- n_het heterogeneous outputs ---------------------------------------------------------------------------------------------
+// ForwardIteration aggregates EVERY heterogeneous variable with the same D_t: agg_j[t] = dot(vec(policy_j[t]), D_t)
+// (ForwardIteration.jl:303-307; BackwardIteration.jl:99-112 keeps one policy sequence per variable). Output 0 is the policy variable
+// of the endogenous dimension (the savings a', KD / A). Output 1 is consumption, the budget residual c = (1+r_t) a + w_t z_e + tr_t
+// - a' (KrusellSmith.jl:80): its aggregate is affine in what the sweeps already reduce,
+//     C_t  = (1+r_t) AD_t + w_t ZD_t + tr_t MD_t - KD_t,      AD_t = sum a D_t (the grid-weighted aggregate), ZD_t = sum z_e D_t, MD_t = sum D_t
+//     dC_t = dr_t AD_t + dw_t ZD_t + dtr_t MD_t + (1+r_t) dAD_t - dKD_t      (ZD_t, MD_t carry no partials: see hank_set_boundary)
+// agg (P, 2) and dagg (P, 2 N) as the sweeps leave them -> out_agg (P, n_het), out_dagg (P, n_het, N) column-major.
+__global__ void k_het_outputs(int P, int n_hh, int n_het, int N, const double *__restrict__ xhh, const double *__restrict__ dxhh,
+                              const double *__restrict__ agg, const double *__restrict__ dagg, const double *__restrict__ zd,
+                              double *__restrict__ out_agg, double *__restrict__ out_dagg) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)P * (N + 1)) return;
+    const int t = (int)(idx % P), n = (int)(idx / P) - 1;
+    const double r = xhh[n_hh * t], w = xhh[n_hh * t + 1], tr = n_hh > 2 ? xhh[n_hh * t + 2] : 0.0;
+    const double KD = agg[t], AD = agg[P + t], ZD = zd[t], MD = zd[P + t];
+    if (n < 0) {
+        if (!out_agg) return;
+        out_agg[t] = KD;
+        if (n_het > 1) out_agg[P + t] = ((1.0 + r) * AD + w * ZD + tr * MD) - KD;
+        return;
+    }
+    if (!out_dagg) return;
+    const double dKD = dagg[(size_t)n * P + t], dAD = dagg[((size_t)N + n) * P + t];
+    const double *dx = dxhh + ((size_t)n * P + t) * n_hh;
+    out_dagg[((size_t)n * n_het) * P + t] = dKD;
+    if (n_het > 1) out_dagg[((size_t)n * n_het + 1) * P + t] = (dx[0] * AD + dx[1] * ZD + (n_hh > 2 ? dx[2] : 0.0) * MD + (1.0 + r) * dAD) - dKD;
+}
+
+static int het_outputs(hank_ctx *ctx, int32_t n_het, const double *dxhh, int32_t N, double *agg_out, double *dagg_out, bool dev) {
+    if (!ctx) return HANK_ERR_BAD_ARG;
+    ENTER(ctx);
+    if (n_het < 1 || n_het > 2 || N < 0 || (!agg_out && !dagg_out)) return fail(ctx, HANK_ERR_BAD_ARG, "n_het must be 1 or 2 (the policy variable, consumption), N >= 0");
+    if (!ctx->primal_done) return fail(ctx, HANK_ERR_NOT_READY, "no primal sweep has been run");
+    const size_t P = ctx->c.P, nh = ctx->c.n_hh;
+    const bool tan = dagg_out && N > 0;
+    if (tan && !dxhh) return fail(ctx, HANK_ERR_BAD_ARG, "the tangent outputs need the dxhh of the last tangent sweep");
+    const double *src = nullptr;
+    if (tan) {
+        if (ctx->last_tan == 2) { if (ctx->wcur && ctx->wcur->valid && ctx->wcur->N == N) src = ctx->wcur->dagg_cm; }
+        else if (ctx->last_tan == 1) { if (ctx->xcur && ctx->xcur->valid && ctx->xcur->N == N) src = ctx->xcur->dagg_cm; }
+        else if (ctx->tw && ctx->tw->valid && ctx->tw->N == N) src = ctx->tw->dagg_cm;
+        if (!src) return fail(ctx, HANK_ERR_NOT_READY, "no tangent sweep with N=%d is current", N);
+    }
+    HIPC(ctx, join_side(ctx));
+    Scratch sc;
+    const double *d_dx = dxhh;
+    double *d_a = agg_out, *d_da = dagg_out;
+    if (!dev) {
+        double *tmp = nullptr;
+        if (tan) {
+            HIPC(ctx, sc.alloc(&tmp, nh * P * N));
+            HIPC(ctx, hipMemcpyAsync(tmp, dxhh, sizeof(double) * nh * P * N, hipMemcpyHostToDevice, ctx->stream));
+            d_dx = tmp;
+            HIPC(ctx, sc.alloc(&d_da, P * n_het * N));
+        }
+        if (agg_out) HIPC(ctx, sc.alloc(&d_a, P * n_het));
+    }
+    const int Nk = tan ? N : 0;
+    hipLaunchKernelGGL(k_het_outputs, dim3((unsigned)((P * (Nk + 1) + 255) / 256)), dim3(256), 0, ctx->stream, (int)P, (int)nh, (int)n_het, Nk, ctx->d_xhh,
+                       d_dx, ctx->d_agg, src, ctx->d_zd, d_a, tan ? d_da : nullptr);
+    HIPC(ctx, hipGetLastError());
+    if (!dev) {
+        if (agg_out) HIPC(ctx, hipMemcpyAsync(agg_out, d_a, sizeof(double) * P * n_het, hipMemcpyDeviceToHost, ctx->stream));
+        if (tan) HIPC(ctx, hipMemcpyAsync(dagg_out, d_da, sizeof(double) * P * n_het * N, hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return HANK_OK;
+}
+extern "C" {
+int hank_get_het_outputs(hank_ctx *ctx, int32_t n_het, const double *dxhh, int32_t N, double *agg_out, double *dagg_out) {
+    return het_outputs(ctx, n_het, dxhh, N, agg_out, dagg_out, false);
+}
+int hank_get_het_outputs_dev(hank_ctx *ctx, int32_t n_het, const double *d_dxhh, int32_t N, double *d_agg_out, double *d_dagg_out) {
+    return het_outputs(ctx, n_het, d_dxhh, N, d_agg_out, d_dagg_out, true);
+}
 }
 
 extern "C" {
@@ -2021,7 +2149,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
     HIPC(ctx, sc.alloc(&R.pol, G)); HIPC(ctx, sc.alloc(&R.lw, G)); HIPC(ctx, sc.alloc(&R.ig, G)); HIPC(ctx, sc.alloc(&R.lo, G));
     HIPC(ctx, sc.alloc(&R.start, (size_t)c.n_e * (c.n_a + 1))); HIPC(ctx, sc.alloc(&R.clo, c.n_e)); HIPC(ctx, sc.alloc(&R.seg, G));
     HIPC(ctx, sc.alloc(&R.lwg, G));
-    HIPC(ctx, sc.alloc(&D[0], G)); HIPC(ctx, sc.alloc(&D[1], G)); HIPC(ctx, sc.alloc(&Dchk, G)); HIPC(ctx, sc.alloc(&aggp, ctx->nbp));
+    HIPC(ctx, sc.alloc(&D[0], G)); HIPC(ctx, sc.alloc(&D[1], G)); HIPC(ctx, sc.alloc(&Dchk, G)); HIPC(ctx, sc.alloc(&aggp, 2 * (size_t)ctx->nbp));
     HIPC(ctx, sc.alloc(&norm, 1)); HIPC(ctx, sc.alloc(&state, 2));
     HIPC(ctx, join_side(ctx));
     HIPC(ctx, hipMemcpyAsync(R.pol, policy, sizeof(double) * G, hipMemcpyHostToDevice, s));

@@ -438,16 +438,22 @@ __device__ inline void dist_step_body(const Consts &c, const Record &R, int t, d
     }
     if (r < n) Dsh[e * RBP + row] = acc;
     lds_barrier();
-    double part = 0.0;
+    // two aggregates of the POST-transition distribution (ForwardIteration.jl:301-307): the policy-weighted one (the heterogeneous
+    // variable itself) and the wealth-GRID-weighted one, sum_pt a(pt) D_t(pt) — with it every heterogeneous output that is affine
+    // in the policy, the state and the household inputs (consumption, cash on hand: BackwardIteration.jl:99-112 routes every key
+    // of the plugin's NamedTuple) is assembled on the host. aggpart: [t][block][2]
+    double part = 0.0, part2 = 0.0;
     if (r < n) {
         const int e2 = e;  // D_new[r,e2] = sum_e D_mid[r,e] * Pi[e,e2]
         double Dn = 0.0;
         Dn = mix_sum(Dn, Dsh + row, RBP, Pish + c.n_e * e2, 1, 0, c.n_e);
         st_mode<HANK_ST_REC>(Dout ? &Dout[(size_t)e2 * n + r] : &R.Dseq[(size_t)(t + 1) * c.G + (size_t)e2 * n + r], Dn);
         part = R.pol[base + (size_t)e2 * n + r] * Dn;
+        part2 = c.a[r] * Dn;
     }
     const double tot = block_sum(part, red, nthr);
-    if (threadIdx.x == 0) aggpart[(size_t)t * nblocks + bid] = tot;
+    const double tot2 = block_sum(part2, red, nthr);
+    if (threadIdx.x == 0) { aggpart[((size_t)t * nblocks + bid) * 2] = tot; aggpart[((size_t)t * nblocks + bid) * 2 + 1] = tot2; }
 }
 __global__ void k_dist_step(Consts c, Record R, int t, double *aggpart) {
     extern __shared__ double sh[];
@@ -738,7 +744,7 @@ k_fused_back(Consts c, Record R, const double *__restrict__ xhh, int *err, int t
 //     tangent), and its aggregate term uses pol[0, e].
 template <int RG, typename VT, bool SS>
 __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanGeom &g, int t, const VT *__restrict__ dDin, VT *__restrict__ dDout,
-          const VT *__restrict__ dpol, VT *__restrict__ aggpart, int bidx_phys, int bidy, int nbx_total, VT (*sh)[16 * 64], double *Pish, VT *red) {
+          const VT *__restrict__ dpol, VT *__restrict__ aggpart, int bidx_phys, int bidy, int nbx_total, VT (*sh)[16 * 64], double *Pish, VT *red, VT *red2) {
     const int nbr_f = (g.nbx + RG - 1) / RG;            // regular blocks; the mass-point blocks behind them keep their place
     const int bidx = (g.N * (int)(sizeof(VT) / 8) <= HANK_XCDMAP_FWD_MAXN && bidx_phys < nbr_f) ? xcd_contiguous(bidx_phys, nbr_f) : bidx_phys;
     const int nthr = 64 * c.n_e;
@@ -930,8 +936,8 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
         for (int q = 0; q < RG; q++) sh[q][e * 64 + lane] = acc[q];
     }
     lds_barrier();
-    VT part;
-    vzero(part);
+    VT part, part2;       // the policy-weighted aggregate's partial and the wealth-grid-weighted one's (see dist_step_body)
+    vzero(part); vzero(part2);
 #pragma unroll
     for (int q = 0; q < RG; q++) {
         if (valid[q]) {
@@ -939,18 +945,23 @@ __device__ inline void tan_fwd_body(const Consts &c, const Record &R, const TanG
             const VT dDn = mix_sum(vmul(Pish[c.n_e * e], sh[q][lane]), &sh[q][lane], 64, Pish + c.n_e * e, 1, 1, c.n_e);
             st_mode<HANK_ST_STATE>(&dDout[((size_t)e * nav + r[q]) * N + n], dDn);
             part = vadd(part, vmul(cp[q], dDn));
+            part2 = vadd(part2, vmul(c.a[r[q] < na ? r[q] : 0], dDn));       // (a virtual row is a part of row 0)
         }
     }
     part = vadd(part, pagg);
     // aggregate of this block: the columns' partials meet in `red` (its own LDS array: no barrier is needed before
     // writing it), ONE barrier, then wave 0 sums over columns and over the RB row lanes of each tangent
     red[e * 64 + lane] = part;
+    red2[e * 64 + lane] = part2;
     lds_barrier();
     if (e == 0) {
-        VT s = red[lane];
-        for (int k = 1; k < c.n_e; k++) s = vadd(s, red[k * 64 + lane]);
-        for (int off = 32; off >= g.NC; off >>= 1) s = vadd(s, vshfl_xor(s, off));
-        if (rl == 0 && nok) aggpart[((size_t)t * nbx_total + bidx) * N + n] = s;
+        VT s = red[lane], s2 = red2[lane];
+        for (int k = 1; k < c.n_e; k++) { s = vadd(s, red[k * 64 + lane]); s2 = vadd(s2, red2[k * 64 + lane]); }
+        for (int off = 32; off >= g.NC; off >>= 1) { s = vadd(s, vshfl_xor(s, off)); s2 = vadd(s2, vshfl_xor(s2, off)); }
+        if (rl == 0 && nok) {       // aggpart: [t][block][2 N]: the first aggregate's N partials, then the second's
+            aggpart[((size_t)t * nbx_total + bidx) * 2 * N + n] = s;
+            aggpart[((size_t)t * nbx_total + bidx) * 2 * N + N + n] = s2;
+        }
     }
 }
 
@@ -959,9 +970,9 @@ __global__ void __launch_bounds__(1024)
 k_tan_fwd(Consts c, Record R, TanGeom g, int t, const VT *__restrict__ dDin, VT *__restrict__ dDout,
           const VT *__restrict__ dpol, VT *__restrict__ aggpart) {
     __shared__ VT sh[RG][16 * 64];
-    __shared__ VT red[16 * 64];
+    __shared__ VT red[16 * 64], red2[16 * 64];
     __shared__ double Pish[256];
-    tan_fwd_body<RG, VT, SS>(c, R, g, t, dDin, dDout, dpol, aggpart, blockIdx.x, blockIdx.y, gridDim.x, sh, Pish, red);
+    tan_fwd_body<RG, VT, SS>(c, R, g, t, dDin, dDout, dpol, aggpart, blockIdx.x, blockIdx.y, gridDim.x, sh, Pish, red, red2);
 }
 
 // the dual-sweep forward launch: blocks [0, nbp) of grid row 0 run the PRIMAL distribution step of
@@ -972,7 +983,7 @@ k_fused_fwd(Consts c, Record R, int tp, int nbp, double *__restrict__ paggpart, 
             const VT *__restrict__ dDin, VT *__restrict__ dDout, const VT *__restrict__ dpol,
             VT *__restrict__ aggpart) {
     __shared__ VT sh[RG][16 * 64];
-    __shared__ VT red[16 * 64];
+    __shared__ VT red[16 * 64], red2[16 * 64];
     __shared__ double Pish[256];
     if ((int)blockIdx.x < nbp) {
         if (blockIdx.y != 0 || tp < 0 || (int)threadIdx.x >= RBP * c.n_e) return;
@@ -980,7 +991,7 @@ k_fused_fwd(Consts c, Record R, int tp, int nbp, double *__restrict__ paggpart, 
         return;
     }
     if (tt < 0) return;
-    tan_fwd_body<RG, VT, SS>(c, R, g, tt, dDin, dDout, dpol, aggpart, blockIdx.x - nbp, blockIdx.y, gridDim.x - nbp, sh, Pish, red);
+    tan_fwd_body<RG, VT, SS>(c, R, g, tt, dDin, dDout, dpol, aggpart, blockIdx.x - nbp, blockIdx.y, gridDim.x - nbp, sh, Pish, red, red2);
 }
 
 // ---- granular tangent halves (hank_backward_step_dual) ---------------------------------------

@@ -151,7 +151,7 @@ struct WideArgs {
     const double *dxhh;     // (n_hh, P, Ntot) column-major: the input tangents as the caller hands them in
     int Ntot, n0;           // workgroup b carries direction n0 + b
     double *dpol;           // [P][Ntot][G] (+ 2 spare) policy partials (written backward, read forward)
-    double *dagg;           // (P, Ntot) column-major (forward sweep)
+    double *dagg;           // (P, 2 Ntot) column-major (forward sweep): the policy-weighted aggregate's columns, then the grid-weighted one's
     // the record is ONE allocation (hank_create): every array is reached through ONE buffer descriptor plus its byte offset from
     // `rec` (a descriptor is four scalar registers; eleven of them, next to the mixing's coefficient stream, spilled)
     const void *rec;
@@ -164,7 +164,7 @@ static inline size_t wide_lds_back(const Consts &c, int kreg) {      // two colu
     return sizeof(double) * (4 * (size_t)WIDE_CS + (size_t)WIDE_CS + 8 * (size_t)c.P + (size_t)wide_kl(c.n_e, kreg) * WIDE_CS);
 }
 static inline size_t wide_lds_fwd(const Consts &c, int kreg) {
-    return sizeof(double) * (4 * (size_t)WIDE_CS + 64 + (size_t)wide_kl(c.n_e, kreg) * WIDE_CS) + sizeof(int) * ((size_t)c.P * c.n_e + 4);
+    return sizeof(double) * (4 * (size_t)WIDE_CS + 96 + (size_t)WIDE_CS + (size_t)wide_kl(c.n_e, kreg) * WIDE_CS) + sizeof(int) * ((size_t)c.P * c.n_e + 4);
 }
 
 // this thread's rows: two pairs of adjacent rows, pair j = rows 2 (j NT + tid), + 1. A lane whose pair lies beyond the grid reads
@@ -348,10 +348,13 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
     double *cHa = xl + 2 * (size_t)CS;                      // [2][CS] ... and to the upper one (two arrays: a gathered term is ONE 8-byte read)
     double *red = xl + 4 * (size_t)CS;                      // [2][16] per-wave sums of the clamped prefix
     double *aggred = red + 32;                              // [2][16] per-wave parts of a period's aggregate
-    double *lst = aggred + 32 + tid;                        // [KL][R][MAXT] this thread's slots of the LDS-resident columns
-    int *closh = reinterpret_cast<int *>(aggred + 32 + (size_t)KL * R * MAXT);      // [P][NE]
+    double *aggred2 = aggred + 32;                          // [2][16] ... and of the grid-weighted one (sum a dD_t: see dist_step_body)
+    double *ash = aggred2 + 32;                             // [CS] the wealth grid (zeros beyond it)
+    double *lst = ash + CS + tid;                           // [KL][R][MAXT] this thread's slots of the LDS-resident columns
+    int *closh = reinterpret_cast<int *>(ash + CS + (size_t)KL * R * MAXT);      // [P][NE]
     for (int k = tid; k < P * NE; k += NT) closh[k] = min(max(Rc.clo[k], 0), na);
-    if (tid < 64) red[tid] = 0.0;                           // red and aggred
+    for (int k = tid; k < CS; k += NT) ash[k] = k < na ? c.a[k] : 0.0;
+    for (int k = tid; k < 96; k += NT) red[k] = 0.0;        // red, aggred and aggred2 (a small grid runs one wave)
     WideRows<R> rw;
     rw.init(NT, tid, na);
     double dD[R][KR];
@@ -397,10 +400,10 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
     load_seg(0, 0, 0);
     int pb = 0;
     double aggBp = 0.0;                     // sum dpol_{t-1} D_{t-1} over this thread's points (waiting for its other half)
-    double *const outn = A.dagg + (size_t)n * P;
+    double *const outn = A.dagg + (size_t)n * P, *const outn2 = A.dagg + ((size_t)A.Ntot + n) * P;      // dagg: (P, 2 Ntot): both aggregates
     for (int t = 0; t < P; t++) {
         WSTAMP(1, t, 0);
-        double aggA = 0.0, aggB = 0.0;
+        double aggA = 0.0, aggB = 0.0, aggA2 = 0.0;
         const int zt = wide_opaque_zero(t, 0);
 #pragma unroll
         for (int e = 0; e < NE; e++) {
@@ -415,11 +418,12 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
                 const double g = S.g[q] * S.dp[q];
                 pl[q] = (1.0 - S.w[q]) * x - g; ph[q] = S.w[q] * x + g;
                 aggA += S.pp[q] * x;                // (t = 0: x = 0)
+                aggA2 += ash[rw.row[q]] * x;
                 aggB += rw.ok[q] ? S.dp[q] * S.Dn[q] : 0.0;
                 cs += (rw.ok[q] && rw.row[q] < clo) ? x : 0.0;
                 wide_pin(pl[q]); wide_pin(ph[q]);
             }
-            wide_pin(aggA); wide_pin(aggB); wide_pin(cs);
+            wide_pin(aggA); wide_pin(aggB); wide_pin(aggA2); wide_pin(cs);
             __builtin_amdgcn_sched_barrier(0);      // (the loads must not be scheduled above the last use of the registers they refill)
             load_src(tn, en, zt);
 #pragma unroll
@@ -435,10 +439,10 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
             xlds_barrier();
             WSTAMP(1, t, 3 + 4 * e);
             if (e == 0 && t >= 2 && tid == 0) {                 // the aggregate of period t-2, whose parts were written at the end of period t-1
-                double s = 0.0;
+                double s = 0.0, s2 = 0.0;
 #pragma unroll
-                for (int k = 0; k < NWM; k++) s += aggred[((t - 1) & 1) * 16 + k];
-                outn[t - 2] = s;
+                for (int k = 0; k < NWM; k++) { s += aggred[((t - 1) & 1) * 16 + k]; s2 += aggred2[((t - 1) & 1) * 16 + k]; }
+                outn[t - 2] = s; outn2[t - 2] = s2;
             }
             // gather: target r sums its sources j in [s0, s2) in order — the upper parts (cH) of [s0, s1), then the lower parts (cL) of [s1, s2)
             double acc[R];
@@ -474,14 +478,14 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
         WSTAMP(1, t, 1);
         // ---- exogenous transition: dD_t[e2] = sum_k dD_mid[k] Pi[k, e2] (ForwardIteration.jl:95-99)
         wide_mix<NE, R, KR, MAXT>(dD, lst, M.m, wide_opaque_zero(t, 1));
-        if (t > 0) {                                            // dagg_{t-1} = sum pol_{t-1} dD_{t-1} + sum dpol_{t-1} D_{t-1}
-            const double s = xwave_reduce63(aggA + aggBp);
-            if (lane == 63) aggred[(t & 1) * 16 + wv] = s;
+        if (t > 0) {                                            // dagg_{t-1} = sum pol_{t-1} dD_{t-1} + sum dpol_{t-1} D_{t-1}; the second aggregate: sum a dD_{t-1}
+            const double s = xwave_reduce63(aggA + aggBp), s2 = xwave_reduce63(aggA2);
+            if (lane == 63) { aggred[(t & 1) * 16 + wv] = s; aggred2[(t & 1) * 16 + wv] = s2; }
         }
         aggBp = aggB;
     }
     // ---- epilogue: the last period's aggregate (its first sum needs pol_{P-1} against the final dD_{P-1})
-    double aggA = 0.0;
+    double aggA = 0.0, aggA2 = 0.0;
 #pragma unroll
     for (int e = 0; e < NE; e++)
 #pragma unroll
@@ -491,15 +495,20 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
             const double x0 = e < KR ? dD[2 * j][e < KR ? e : 0] : lst[((e - KR) * R + 2 * j) * MAXT];
             const double x1 = e < KR ? dD[2 * j + 1][e < KR ? e : 0] : lst[((e - KR) * R + 2 * j + 1) * MAXT];
             aggA += p0 * x0 + p1 * x1;                          // (zeros beyond the grid)
+            aggA2 += ash[rw.row[2 * j]] * x0 + ash[rw.row[2 * j + 1]] * x1;
         }
-    const double s = xwave_reduce63(aggA + aggBp);
-    if (lane == 63) aggred[(P & 1) * 16 + wv] = s;
+    const double s = xwave_reduce63(aggA + aggBp), s2 = xwave_reduce63(aggA2);
+    if (lane == 63) { aggred[(P & 1) * 16 + wv] = s; aggred2[(P & 1) * 16 + wv] = s2; }
     __syncthreads();
     if (tid == 0) {
-        if (P >= 2) { double v = 0.0; for (int k = 0; k < NWM; k++) v += aggred[((P - 1) & 1) * 16 + k]; outn[P - 2] = v; }
-        double v = 0.0;
-        for (int k = 0; k < NWM; k++) v += aggred[(P & 1) * 16 + k];
-        outn[P - 1] = v;
+        if (P >= 2) {
+            double v = 0.0, v2 = 0.0;
+            for (int k = 0; k < NWM; k++) { v += aggred[((P - 1) & 1) * 16 + k]; v2 += aggred2[((P - 1) & 1) * 16 + k]; }
+            outn[P - 2] = v; outn2[P - 2] = v2;
+        }
+        double v = 0.0, v2 = 0.0;
+        for (int k = 0; k < NWM; k++) { v += aggred[(P & 1) * 16 + k]; v2 += aggred2[(P & 1) * 16 + k]; }
+        outn[P - 1] = v; outn2[P - 1] = v2;
     }
 }
 

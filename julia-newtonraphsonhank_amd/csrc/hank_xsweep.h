@@ -1152,8 +1152,8 @@ struct XSweepFwdArgs {
     const double *dpol;         // D > 0: [P][groups][G][D]
     int groups;
     double *Dvirt;              // VAL: [P][n_e][64] the mass kept on the virtual rows (k_xfix_D)
-    double *aggpart;            // VAL: [P][members]
-    double *daggpart;           // D > 0: [P][members][XG*D]
+    double *aggpart;            // VAL: [P][members][2]
+    double *daggpart;           // D > 0: [P][members][2*XG*D]
     const int *src;             // [P][members] lo | hi << 8 | (some column clamped) << 16 | (member 0 records row 0's full mass) << 17 | units << 18
     const int2 *units;          // [P][members][XUCAP] {e | ja << 4 | cnt << 16, ta | tb << 8 | nv << 16}
     int all_members;            // dev knob: every period waits for every member
@@ -1176,9 +1176,12 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     // (round 5) the aggregate's terms of a period, per lane: the column waves leave them here and the SYNC wave — idle between its
     // polls — sums them over the columns and the lanes one period later. As eleven waves' own reductions they were 105 of the 562
     // VALU instructions a wave issues per period, three waves deep on a SIMD.
-    constexpr int NAP = NSL == 1 ? 1 : ((NSL + 1) / 2) * 2;                 // terms per lane (padded to 16-byte pairs)
-    double *aggsh = Pish + ((ne * ne + 1) & ~1);        // [2][ne][64][NAP]
-    int *closh = reinterpret_cast<int *>(aggsh + 2 * (size_t)ne * 64 * NAP);       // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
+    // Two aggregates per slot (see dist_step_body): the policy-weighted one and the wealth-grid-weighted one. ONE buffer is enough:
+    // the sync wave reads it between the period's first barrier and its own all-member poll, which stands in front of the barrier
+    // the column waves must pass before they write the next period's terms.
+    constexpr int NAP = 2 * NSL;                        // terms per lane: NSL of the first aggregate, NSL of the second
+    double *aggsh = Pish + ((ne * ne + 1) & ~1);        // [ne][64][NAP]
+    int *closh = reinterpret_cast<int *>(aggsh + (size_t)ne * 64 * NAP);           // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
     int *srcsh = closh + (size_t)P * ne;                // [P]
     int *ctl = srcsh + P;
     const XGroup g = xgroup_join(A.sy, ctl);
@@ -1208,6 +1211,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     const bool virt = !syncw && lane == 63;             // this wave's virtual row: part of the mass point (row 0) kept by this member
     const bool live = own || virt;
     const size_t pt = (size_t)e * na + (own ? r : 0);
+    const double xar = c.a[own ? r : 0];                // this row's grid point (a virtual row is a part of row 0)
     // state layout [e][member][64][SP]: a member's 63 rows and its virtual row (slot 63) are ONE line-aligned block
     const size_t GM = (size_t)ne * Sact * 64;
     const size_t gx = (size_t)x * GM;
@@ -1329,7 +1333,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     (void)son;
     // the aggregate of period tp from the lanes' terms (sync wave; fixed order: columns ascending, then the lanes' DPP tree)
     auto reduce_agg = [&](int tp) {
-        const double *ap = aggsh + ((size_t)(tp & 1) * ne * 64 + lane) * NAP;
+        const double *ap = aggsh + (size_t)lane * NAP;
         double sk[NAP];
 #pragma unroll
         for (int k = 0; k < NAP; k++) sk[k] = 0.0;
@@ -1345,14 +1349,14 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         }
         const size_t pb = (size_t)tp * Sact + cW;
 #pragma unroll
-        for (int k = 0; k < D; k++) {
-            const double pd = xwave_reduce63(sk[k]);
-            if (lane == 63) A.daggpart[pb * (size_t)(XG * D) + x * D + k] = pd;
+        for (int k = 0; k < D; k++) {       // daggpart: [P][members][2 W], W = XG * D: the first aggregate's partials, then the second's
+            const double pd = xwave_reduce63(sk[k]), pd2 = xwave_reduce63(sk[NSL + k]);
+            if (lane == 63) { A.daggpart[pb * (size_t)(2 * XG * D) + x * D + k] = pd; A.daggpart[pb * (size_t)(2 * XG * D) + XG * D + x * D + k] = pd2; }
         }
         if constexpr (VAL) {
             if (recD) {
-                const double pD = xwave_reduce63(sk[IV]);
-                if (lane == 63) A.aggpart[pb] = pD;
+                const double pD = xwave_reduce63(sk[IV]), pD2 = xwave_reduce63(sk[NSL + IV]);
+                if (lane == 63) { A.aggpart[2 * pb] = pD; A.aggpart[2 * pb + 1] = pD2; }
             }
         }
     };
@@ -1484,6 +1488,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
                     else if (virt) A.Dvirt[((size_t)t * ne + e) * 64 + cW] = mx[IV];
                     // aggregate on the POST-transition distribution (ForwardIteration.jl:301-307); a virtual row carries row 0's policy
                     at[IV] = live ? polr * mx[IV] : 0.0;
+                    at[NSL + IV] = live ? xar * mx[IV] : 0.0;
                 }
             }
             // aggregate partials: pol_t dD_t + dpol_t D_t. Value carried: a row's own policy partials meet its new D_t here (a
@@ -1495,8 +1500,9 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
                 if constexpr (VAL) term = live ? (polr * mx[k] + dpr[k] * mx[IV]) : 0.0;
                 else term = (term + pagg[k]) + ((own && r < clo) ? dpr[k] * Dr : 0.0);
                 at[k] = term;
+                at[NSL + k] = live ? xar * mx[k] : 0.0;      // the grid-weighted aggregate's partial: sum a dD_t
             }
-            xtile_store<NAP>(aggsh + (((size_t)(t & 1) * ne + e) * 64 + lane) * NAP, at);      // summed by the sync wave in the next period (reduce_agg)
+            xtile_store<NAP>(aggsh + ((size_t)e * 64 + lane) * NAP, at);      // summed by the sync wave in the next period (reduce_agg)
 #pragma unroll
             for (int k = 0; k < NSL; k++) mxp[k] = mx[k];
         }
@@ -1655,11 +1661,11 @@ __global__ void k_xfix_D(Consts c, double *Dseq, const double *Dvirt, int Sact) 
 }
 
 // dagg of one pass [P][XG*D] -> columns [n0, n0+N) of the caller's (P, Ntot) column-major block
-__global__ void k_xout(const double *__restrict__ dagg, int P, int W, int n0, int N, double *__restrict__ out) {
+__global__ void k_xout(const double *__restrict__ dagg, int P, int W, int src0, int n0, int N, double *__restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= P * N) return;
     const int n = idx / P, t = idx - n * P;
-    out[(size_t)(n0 + n) * P + t] = dagg[(size_t)t * W + n];
+    out[(size_t)(n0 + n) * P + t] = dagg[(size_t)t * W + src0 + n];
 }
 
 // (G,P,N) col-major export of one pass's dpol [P][groups][G][D] into columns [n0, n0+N)

@@ -26,7 +26,8 @@ ABI_SYMBOLS = (
     "hank_create", "hank_create_on", "hank_gather_columns", "hank_destroy", "hank_last_error", "hank_n_hh", "hank_set_stream", "hank_sync",
     "hank_set_boundary", "hank_primal", "hank_jvp", "hank_primal_dev", "hank_jvp_dev", "hank_check",
     "hank_primal_jvp", "hank_primal_jvp_dev",
-    "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_backward_step",
+    "hank_get_policy_seq", "hank_get_dpolicy_seq", "hank_get_dist_seq", "hank_get_het_outputs", "hank_get_het_outputs_dev",
+    "hank_get_grid_aggregates", "hank_get_grid_aggregates_dev", "hank_backward_step",
     "hank_backward_step_dual", "hank_forward_step", "hank_forward_step_dual", "hank_last_timings", "hank_stats", "hank_info", "hank_vfi", "hank_stationary_dist", "hank_fake_news", "hank_device_available",
 )
 
@@ -97,6 +98,10 @@ def load_library() -> C.CDLL:
     lib.hank_get_policy_seq.argtypes = [vp, dp]
     lib.hank_get_dpolicy_seq.argtypes = [vp, i32, dp]
     lib.hank_get_dist_seq.argtypes = [vp, dp]
+    lib.hank_get_het_outputs.argtypes = [vp, i32, dp, i32, dp, dp]
+    lib.hank_get_het_outputs_dev.argtypes = [vp, i32, vp, i32, vp, vp]
+    lib.hank_get_grid_aggregates.argtypes = [vp, dp, i32, dp]
+    lib.hank_get_grid_aggregates_dev.argtypes = [vp, vp, i32, vp]
     lib.hank_backward_step.argtypes = [vp, dp, dp, dp, dp]
     lib.hank_backward_step_dual.argtypes = [vp, dp, dp, dp, dp, i32, dp, dp, dp, dp]
     lib.hank_forward_step.argtypes = [vp, dp, dp, dp, dp]
@@ -311,6 +316,34 @@ class HouseholdBlock:
         out = np.empty((self.n_a, self.n_e, self.P, N), order="F")
         self._chk(self._lib.hank_get_dpolicy_seq(self._ctx, int(N), _p(out)))
         return out
+
+    def het_outputs(self, n_het: int = 2, dxhh=None):
+        """every heterogeneous variable's aggregate of the last sweeps (hank_get_het_outputs; ForwardIteration.jl:303-307):
+        output 0 the policy variable (KD / A), output 1 consumption. -> agg (P, n_het), and dagg (P, n_het, N) when `dxhh`
+        (n_hh, P, N) — the input of the last tangent sweep — is given (else None)."""
+        agg = np.empty((self.P, n_het), order="F")
+        if dxhh is None:
+            self._chk(self._lib.hank_get_het_outputs(self._ctx, int(n_het), None, 0, _p(agg), None))
+            return agg, None
+        dxhh = np.asfortranarray(dxhh, dtype=np.float64)
+        if dxhh.ndim != 3 or dxhh.shape[:2] != (self.n_hh, self.P):
+            raise ValueError(f"dxhh must be ({self.n_hh}, {self.P}, N), got {dxhh.shape}")
+        N = dxhh.shape[2]
+        dagg = np.empty((self.P, n_het, N), order="F")
+        self._chk(self._lib.hank_get_het_outputs(self._ctx, int(n_het), _p(dxhh), N, _p(agg), _p(dagg)))
+        return agg, dagg
+
+    def het_outputs_dev(self, n_het: int, d_dxhh: int, N: int, d_agg: int, d_dagg: int):
+        """device-pointer form (asynchronous on the context's stream)."""
+        self._chk(self._lib.hank_get_het_outputs_dev(self._ctx, int(n_het), d_dxhh or None, int(N), d_agg or None, d_dagg or None))
+
+    def grid_aggregates(self, N: int = 0):
+        """the grid-weighted aggregate sum_pt a(pt) D_t(pt) of the last primal sweep, and (N > 0) its partials (P, N) of the
+        last tangent sweep (hank_get_grid_aggregates)."""
+        agg2 = np.empty(self.P)
+        dagg2 = np.empty((self.P, N), order="F") if N > 0 else None
+        self._chk(self._lib.hank_get_grid_aggregates(self._ctx, _p(agg2), int(N), _p(dagg2) if N > 0 else None))
+        return agg2, dagg2
 
     def fake_news(self):
         """the household block's Jacobian at the steady state from its Toeplitz structure (hank_fake_news):

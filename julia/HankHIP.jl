@@ -28,11 +28,14 @@ mutable struct HankCtx
     ptr::Ptr{Cvoid}
     P::Int; G::Int; n_a::Int; n_e::Int
     hh_rows::Tuple        # names of the xVals rows the native family reads, in the order the library expects
+    outputs::Tuple        # the heterogeneous variables the family returns, in the order of hank_get_het_outputs
 end
 
-# native kernel families by value-function name: id (include/hank_hip.h) and the household inputs it reads
-const _FAMILIES = Dict(:ValueFunction => (0, (:r, :w)),                # KrusellSmith.jl:43-83, :53-54
-                       :HANKValueFunction => (1, (:r, :om, :Tr)))      # one-asset HANK (not in the reference)
+# native kernel families by value-function name: id (include/hank_hip.h), the household inputs it reads, and the heterogeneous
+# variables it returns (output 1 = the policy variable of the endogenous dimension, output 2 = consumption, the c_grid of
+# KrusellSmith.jl:79 returned as a second policy: hank_get_het_outputs)
+const _FAMILIES = Dict(:ValueFunction => (0, (:r, :w), (:KD, :C)),                # KrusellSmith.jl:43-83, :53-54
+                       :HANKValueFunction => (1, (:r, :om, :Tr), (:A, :C)))      # one-asset HANK (not in the reference)
 
 # one device context per (SequenceModel, HIP device); device -1 = the current one. Keyed on the model ITSELF (an IdDict keeps it
 # alive: an objectid can be recycled by a later model and hand it a context built for other grids) and guarded by a lock:
@@ -54,7 +57,7 @@ function hank_context(model::SequenceModel; device::Union{Nothing,Integer} = not
         w = model.heterogeneity.wealth; p = model.heterogeneity.productivity
         a = collect(Float64, w.grid); z = collect(Float64, p.grid); Π = Matrix{Float64}(p.transition)
         haskey(_FAMILIES, nameof(model.value_fn)) || error("no native kernel family for $(model.value_fn)")
-        fam_id, rows = _FAMILIES[nameof(model.value_fn)]
+        fam_id, rows, outs = _FAMILIES[nameof(model.value_fn)]
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         GC.@preserve a z Π begin
             m = HankModelC(w.n, p.n, model.compspec.T, fam_id, pointer(a), pointer(z), pointer(Π),
@@ -64,7 +67,7 @@ function hank_context(model::SequenceModel; device::Union{Nothing,Integer} = not
                 ccall((:hank_create_on, LIBHANK), Cint, (Ref{HankModelC}, Int32, Ref{Ptr{Cvoid}}), m, Int32(device), ref)
         end
         _check(ref[], rc)
-        ctx = HankCtx(ref[], model.compspec.T - 1, w.n * p.n, w.n, p.n, rows)
+        ctx = HankCtx(ref[], model.compspec.T - 1, w.n * p.n, w.n, p.n, rows, outs)
         @assert ccall((:hank_n_hh, LIBHANK), Cint, (Ptr{Cvoid},), ref[]) == length(rows)
         finalizer(c -> ccall((:hank_destroy, LIBHANK), Cint, (Ptr{Cvoid},), c.ptr), ctx)
         ctx
@@ -90,6 +93,8 @@ mutable struct DevicePolicySeqs{TF}
     ctx::HankCtx; het_keys::Tuple; N::Int
     xhh::Matrix{Float64}; dxhh::Union{Nothing,Array{Float64,3}}; value::Matrix{Float64}
     D0::Union{Nothing,Vector{Float64}}; agg::Union{Nothing,Vector{Float64}}; dagg::Union{Nothing,Matrix{Float64}}
+    aggs::Union{Nothing,Matrix{Float64}}; daggs::Union{Nothing,Array{Float64,3}}      # (P, n_het), (P, n_het, N): models with two heterogeneous variables
+    grids::Tuple{Vector{Float64},Vector{Float64}}                                      # wealth and productivity grids (consumption policy)
 end
 
 # a Dual of the caller's own type TF = Dual{Tag,Float64,N} from a value and N partials: the inner
@@ -110,6 +115,13 @@ function _run_block!(s::DevicePolicySeqs, D0::Vector{Float64})
                               ctx.ptr, s.xhh, s.dxhh, s.N, agg, dagg))
     end
     s.D0, s.agg, s.dagg = D0, agg, dagg
+    if length(s.het_keys) > 1     # every heterogeneous variable's aggregate, reduced by the same sweeps (ForwardIteration.jl:303-307)
+        n_het = length(ctx.outputs)
+        s.aggs = Matrix{Float64}(undef, ctx.P, n_het)
+        s.daggs = s.dxhh === nothing ? nothing : Array{Float64}(undef, ctx.P, n_het, s.N)
+        _check(ctx.ptr, ccall((:hank_get_het_outputs, LIBHANK), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}),
+                              ctx.ptr, Int32(n_het), s.dxhh === nothing ? C_NULL : s.dxhh, Int32(s.N), s.aggs, s.daggs === nothing ? C_NULL : s.daggs))
+    end
     return s
 end
 
@@ -123,7 +135,8 @@ function BackwardIteration(xVec_endog, exog_paths::NamedTuple, model::SequenceMo
     N = TF <: Dual ? length(partials(first(xVec_endog))) : 0
     dxhh = N > 0 ? Float64[partials(xd[k, t])[n] for k in 1:size(xd, 1), t in 1:ctx.P, n in 1:N] : nothing   # (n_hh, P, N)
     s = DevicePolicySeqs{TF}(ctx, vars_of_type(model, :heterogeneous), N, xhh, dxhh, Matrix{Float64}(ss_end.value),
-                             nothing, nothing, nothing)
+                             nothing, nothing, nothing, nothing, nothing,
+                             (collect(Float64, model.heterogeneity.wealth.grid), collect(Float64, model.heterogeneity.productivity.grid)))
     ss_initial === nothing || _run_block!(s, Vector{Float64}(ss_initial.D))
     return s
 end
@@ -135,21 +148,42 @@ function Base.getproperty(s::DevicePolicySeqs{TF}, k::Symbol) where {TF}
     getfield(s, :agg) === nothing && _run_block!(s, fill(1.0 / ctx.G, ctx.G))     # read before ForwardIteration
     pol = Array{Float64}(undef, ctx.n_a, ctx.n_e, ctx.P)
     _check(ctx.ptr, ccall((:hank_get_policy_seq, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Float64}), ctx.ptr, pol))
-    N == 0 && return [pol[:, :, t] for t in 1:ctx.P]
-    dpol = Array{Float64}(undef, ctx.n_a, ctx.n_e, ctx.P, N)
-    _check(ctx.ptr, ccall((:hank_get_dpolicy_seq, LIBHANK), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ctx.ptr, N, dpol))
-    return [[_mkdual(TF, pol[a, e, t], ntuple(n -> dpol[a, e, t, n], N)) for a in 1:ctx.n_a, e in 1:ctx.n_e] for t in 1:ctx.P]
+    seq = if N == 0
+        [pol[:, :, t] for t in 1:ctx.P]
+    else
+        dpol = Array{Float64}(undef, ctx.n_a, ctx.n_e, ctx.P, N)
+        _check(ctx.ptr, ccall((:hank_get_dpolicy_seq, LIBHANK), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), ctx.ptr, N, dpol))
+        [[_mkdual(TF, pol[a, e, t], ntuple(n -> dpol[a, e, t, n], N)) for a in 1:ctx.n_a, e in 1:ctx.n_e] for t in 1:ctx.P]
+    end
+    k == ctx.outputs[1] && return seq
+    k == :C || error("the native family returns $(ctx.outputs), not :$k")
+    # consumption, the budget residual of KrusellSmith.jl:79: (1 + r) .* policy_a .+ (w .* labor_mat [.+ tr]) .- griddedpolicy
+    xhh = getfield(s, :xhh); dxhh = getfield(s, :dxhh)
+    xin(j, t) = N == 0 ? xhh[j, t] : _mkdual(TF, xhh[j, t], ntuple(n -> dxhh[j, t, n], N))
+    grid = getfield(s, :grids)[1]; z = getfield(s, :grids)[2]
+    return [[(1 + xin(1, t)) * grid[a] + (xin(2, t) * z[e] + (size(xhh, 1) > 2 ? xin(3, t) : 0.0)) - seq[t][a, e]
+             for a in 1:ctx.n_a, e in 1:ctx.n_e] for t in 1:ctx.P]
 end
 
 # same signature as ForwardIteration.jl:253-255 for sequences that came from BackwardIteration above:
 # this is where the ONE fused sweep of a fullFunction evaluation runs (NewtonRaphson.jl:78-79)
 function ForwardIteration(seqs::DevicePolicySeqs{TF}, model::SequenceModel, ss_initial) where {TF}
-    length(seqs.het_keys) == 1 || error("the fused device sweep aggregates one heterogeneous variable (got $(seqs.het_keys))")
+    all(k -> k in seqs.ctx.outputs, seqs.het_keys) || error("the native family returns $(seqs.ctx.outputs) (got $(seqs.het_keys))")
     D0 = Vector{Float64}(ss_initial.D)
     (seqs.agg === nothing || D0 != seqs.D0) && _run_block!(seqs, D0)
-    agg, dagg = seqs.agg, seqs.dagg
-    out = seqs.N == 0 ? agg : [_mkdual(TF, agg[t], ntuple(n -> dagg[t, n], seqs.N)) for t in 1:length(agg)]
-    return NamedTuple{seqs.het_keys}((out,))
+    if length(seqs.het_keys) == 1
+        agg, dagg = seqs.agg, seqs.dagg
+        out = seqs.N == 0 ? agg : [_mkdual(TF, agg[t], ntuple(n -> dagg[t, n], seqs.N)) for t in 1:length(agg)]
+        return NamedTuple{seqs.het_keys}((out,))
+    end
+    # one aggregate per heterogeneous variable, each its own policy dotted with the same D_t (ForwardIteration.jl:303-307)
+    aggs, daggs = seqs.aggs, seqs.daggs
+    col(k) = findfirst(==(k), seqs.ctx.outputs)
+    outs = map(seqs.het_keys) do k
+        j = col(k)
+        seqs.N == 0 ? aggs[:, j] : [_mkdual(TF, aggs[t, j], ntuple(n -> daggs[t, j, n], seqs.N)) for t in 1:size(aggs, 1)]
+    end
+    return NamedTuple{seqs.het_keys}(Tuple(outs))
 end
 
 # ---- one process, several GPUs (GeneralStructures.jl:542-550: JVP is linear in `tangent`, so tangent columns shard) ----------
@@ -181,6 +215,24 @@ function sharded_jvp_columns(model::SequenceModel, ss_end, ss_initial, xhh::Matr
         end
     end
     return dagg
+end
+
+# The same with the blocks left in HBM and assembled on ONE GPU over xGMI (hank_gather_columns): `d_blocks[k]` is the device pointer
+# of context k's (P, N_k[k]) block as hank_jvp_dev / hank_primal_jvp_dev wrote it, `d_out` a (P, sum N_k) buffer on ctxs[1]'s device.
+# Asynchronous: hank_sync(ctxs[1]) — or work on its stream — sees the assembled matrix.
+function gather_columns!(ctxs::Vector{HankCtx}, d_blocks::Vector{Ptr{Float64}}, N_k::Vector{Int32}, d_out::Ptr{Float64})
+    ptrs = Ptr{Cvoid}[c.ptr for c in ctxs]
+    _check(ctxs[1].ptr, ccall((:hank_gather_columns, LIBHANK), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Ptr{Float64}}, Ptr{Int32}, Ptr{Float64}),
+                              ptrs, Int32(length(ctxs)), d_blocks, N_k, d_out))
+    return d_out
+end
+
+# which kernel family ran the last tangent sweep and how the context is configured (hank_info): (last_tangent_family, wide_mode,
+# wide_min, wide_supported, xjvp_max, record_diet, record_bytes, 0); families: 0 per-period launches, 1 XCD-persistent, 2 on-chip wide
+function hank_info(ctx::HankCtx)
+    out = zeros(Int64, 8)
+    _check(ctx.ptr, ccall((:hank_info, LIBHANK), Cint, (Ptr{Cvoid}, Ptr{Int64}), ctx.ptr, out))
+    return out
 end
 
 # ---- the household block of getSteadyStateJacobian (SteadyStateJacobian.jl:187-256, :293-323, :358-387) ------------------------

@@ -397,6 +397,54 @@ void FN(orc_forward_iteration)(const orc_model *m, int P, const double *policy_s
     free(Dn);
 }
 
+/* ---- more than one heterogeneous variable (BackwardIteration.jl:99-112, ForwardIteration.jl:303-307) ------------
+ * A value function that returns (Value, KD, C) keeps one policy sequence per variable; ForwardIteration moves D_t with
+ * the endogenous dimension's policy variable and aggregates EVERY variable with the same D_t:
+ * agg_j[t] = dot(vec(policy_j[t]), D_t). The reference ships no two-output plugin: consumption here is the c_grid its
+ * KS plugin already forms at KrusellSmith.jl:79, returned as a second policy. Parity unpinned by construction.       */
+/* c_grid of every period from the savings policies: (1 + r) .* policy_a .+ (w .* labor_mat [.+ tr]) .- griddedpolicy */
+void FN(orc_consumption_policy)(const orc_model *m, int P, const double *xr_, const double *xw_, const double *xt_,
+                                const double *policy_seq_, double *cons_seq_) {
+    const int n_a = m->n_a, n_e = m->n_e;
+    const size_t G = (size_t)n_a * n_e;
+    const dual *xr = (const dual *)xr_, *xw = (const dual *)xw_, *xt = (const dual *)xt_;
+    const dual *pol = (const dual *)policy_seq_;
+    dual *cons = (dual *)cons_seq_;
+    for (int t = 0; t < P; t++) {
+        dual one_plus_r = d_add_r(xr[t], 1.0);
+        for (int e = 0; e < n_e; e++) {
+            dual inc = d_mul_r(xw[t], m->z[e]);
+            if (xt) inc = d_add(inc, xt[t]);
+            for (int ia = 0; ia < n_a; ia++)
+                cons[(size_t)t * G + e * n_a + ia] = d_sub(d_add(d_mul_r(one_plus_r, m->a[ia]), inc), pol[(size_t)t * G + e * n_a + ia]);
+        }
+    }
+}
+/* policy_seqs_: n_het sequences of P x G duals, the endogenous dimension's policy variable first; agg_: [n_het][P] duals */
+void FN(orc_forward_iteration_het)(const orc_model *m, int P, int n_het, const double *policy_seqs_,
+                                   const double *ss_init_D, double *agg_) {
+    const int G = m->n_a * m->n_e;
+    const dual *seqs = (const dual *)policy_seqs_;
+    dual *agg = (dual *)agg_;
+    dual *D = (dual *)malloc(sizeof(dual) * (size_t)G);
+    dual *Dn = (dual *)malloc(sizeof(dual) * (size_t)G);
+    for (int i = 0; i < G; i++) D[i] = d_const(ss_init_D[i]);
+    for (int t = 0; t < P; t++) {
+        FN(orc_transition_step)(m, (const double *)(seqs + (size_t)t * G), (const double *)D, (double *)Dn);
+        dual *tmp = D;
+        D = Dn;
+        Dn = tmp;
+        for (int j = 0; j < n_het; j++) {
+            const dual *pol = seqs + ((size_t)j * P + t) * G;
+            dual s = d_const(0.0);
+            for (int i = 0; i < G; i++) s = d_add(s, d_mul(pol[i], D[i]));
+            agg[(size_t)j * P + t] = s;
+        }
+    }
+    free(D);
+    free(Dn);
+}
+
 /* ---- household block: BackwardIteration -> ForwardIteration (NewtonRaphson.jl:78-79) ------ */
 int FN(orc_household_block)(const orc_model *m, int P, const double *xr, const double *xw,
                             const double *ss_end_value, const double *ss_init_D, double *agg,

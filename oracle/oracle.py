@@ -167,6 +167,24 @@ class Oracle:
         agg = self.forward_iteration(pol, ss_init_D, N)
         return st, agg, pol
 
+    def household_block_het(self, xr, xw, ss_end_value, ss_init_D, N: int, xt=None):
+        """the household block of a value function with TWO heterogeneous variables, savings and consumption (the c_grid of
+        KrusellSmith.jl:79 returned as a policy): BackwardIteration keeps one policy sequence per variable
+        (BackwardIteration.jl:99-112), ForwardIteration aggregates each with the same D_t (ForwardIteration.jl:303-307).
+        -> (status, agg (2, P, 1+N), policy_seq, cons_seq)."""
+        st, pol = self.backward_iteration(xr, xw, ss_end_value, N, xt)
+        P = pol.shape[0]
+        ps = np.ascontiguousarray(pol.transpose(0, 2, 1, 3))
+        cons = np.empty_like(ps)
+        xr = np.ascontiguousarray(xr, dtype=np.float64); xw = np.ascontiguousarray(xw, dtype=np.float64)
+        xt_ = None if xt is None else np.ascontiguousarray(xt, dtype=np.float64)
+        _fn("orc_consumption_policy", N)(C.byref(self.m), P, _dp(xr), _dp(xw), None if xt_ is None else _dp(xt_), _dp(ps), _dp(cons))
+        seqs = np.ascontiguousarray(np.stack([ps, cons]))
+        D0 = np.ascontiguousarray(np.asarray(ss_init_D, dtype=np.float64).reshape((self.n_a, self.n_e), order="F").T)
+        agg = np.empty((2, P, 1 + N))
+        _fn("orc_forward_iteration_het", N)(C.byref(self.m), P, 2, _dp(seqs), _dp(D0), _dp(agg))
+        return st, agg, pol, cons.transpose(0, 2, 1, 3).copy()
+
     def ks_full_function(self, x, Z, alpha, delta, KS_ss_start, ss_end_value, ss_init_D, N: int):
         """fullFunction of y_Iteration for KrusellSmith.yaml (NewtonRaphson.jl:77-83).
         x: (4, P, 1+N) duals of (Y, KS, r, w). Returns (status, F (4,P,1+N), agg (P,1+N))."""
