@@ -15,6 +15,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def hank():
+    try:                                # torch's HIP runtime must be up before libhank_hip loads its own (a GPU test that moves a
+        import torch                    # tensor to the device after the library has loaded finds "No HIP GPUs" otherwise)
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:                   # noqa: BLE001
+        pass
     import hank_amd
     return hank_amd
 
