@@ -684,12 +684,18 @@ def main(argv=None):
             except Exception as e:      # noqa: BLE001 - the headline line must survive a failure of the side measurements
                 out["extra"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if use_dist:
+        # every rank gives its GPU back BEFORE the last barrier: the device-group child below runs persistent sweeps on all of
+        # them, and a persistent sweep must find its XCD's CUs free (a rank still running kernels there could cost the child a
+        # group, i.e. a fallback to the launches or a failed check; the child reports hank_stats of every context next to its number)
+        hb.set_stream(None)
+        hb.sync()
+        torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         if world > 1 and not args.no_extra:
             # the same partition with ONE process driving one context per GPU (no collective), measured in a fresh child once
-            # the ranks are done with the GPUs: a failure there must not cost the headline line
+            # the ranks are done with the GPUs (idle behind the barrier above): a failure there must not cost the headline line
             import subprocess
             try:
                 cmd = [sys.executable, str(Path(__file__).resolve()), "--mode", "devicegroup", "--gpus", str(world), "--steps", str(args.steps),

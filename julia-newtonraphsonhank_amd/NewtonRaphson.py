@@ -204,7 +204,14 @@ def warm_linear_solver(n_unknowns: int):
         pass
 
 
-def _device_inverse_solver(J):
+def release_linear_solver():
+    """drop the factorisations kept for a J̅ (the host LU and the device inverse: n² fp64 in HBM, 97 MB at n = 3 493).
+    NewtonRaphsonHANK calls it when it returns; a caller that drives y_Iteration itself calls it when done with a J̅."""
+    _LU_CACHE[:] = []
+    _INV_CACHE[:] = []
+
+
+def _device_inverse_solver(J, device=None):
     """J̅⁻¹·b as ONE dense matrix-vector product on the GPU (a library GEMV: torch → rocBLAS) with the explicit inverse, formed once
     per J̅ (torch.linalg.inv on the device): at the one-asset HANK size (n = 3 493) the host's two triangular solves read 97 MB per
     inner iteration and took as long as the device's tangent sweeps (2.1 ms against 2.9 ms, scripts/dev_profile_newton.py). J̅⁻¹
@@ -215,11 +222,11 @@ def _device_inverse_solver(J):
             return None
     except Exception:       # noqa: BLE001
         return None
-    if not (_INV_CACHE and _INV_CACHE[0][0] is J):
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))       # the MODEL's GPU (hank_create_on), not torch's current one
+    if not (_INV_CACHE and _INV_CACHE[0][0] is J and _INV_CACHE[0][2] == dev):
         import time
         t0 = time.perf_counter()
         A = J.toarray() if hasattr(J, "toarray") else np.asarray(J)
-        dev = torch.device("cuda", torch.cuda.current_device())
         Ainv = torch.linalg.inv(torch.from_numpy(np.ascontiguousarray(A, dtype=np.float64)).to(dev))
         (Ainv[:1] @ Ainv[:, :1]).cpu()      # the first product of a process also loads rocBLAS: count it with the set-up, not with an iteration
         # once per J̅ (and, the first time in a process, the linear-algebra libraries' own start-up: 0.15-0.35 s against 40 ms warm at
@@ -229,7 +236,7 @@ def _device_inverse_solver(J):
         def apply(b, Ainv=Ainv, dev=dev):
             return (Ainv @ torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).to(dev)).cpu().numpy()
 
-        _INV_CACHE[:] = [(J, apply)]
+        _INV_CACHE[:] = [(J, apply, dev)]
     return _INV_CACHE[0][1]
 
 
@@ -251,7 +258,7 @@ def y_Iteration(J̅, x, y0, exog_paths, mod: SequenceModel, ss_initial, ss_endin
     i = 1
     solve = None
     if linear_solver in ("auto", "device") and len(y) >= 2000:      # (below that the host's LU solve takes a tenth of a millisecond)
-        solve = _device_inverse_solver(J̅)
+        solve = _device_inverse_solver(J̅, getattr(lin.hb, "device", None))
     if solve is None and linear_solver in ("auto", "lu", "device"):
         solve = _lu_solver(J̅)
     if inner == "krylov":
@@ -308,11 +315,14 @@ def NewtonRaphsonHANK(x_0, J̅, exog_paths, mod: SequenceModel, ss_initial, ss_e
     x = np.asarray(x_0, dtype=np.float64)
     y = x.copy()
     i = 1
-    while ε < np.linalg.norm(y) and i < 100:
-        y = y_Iteration(J̅, x, y, exog_paths, mod, ss_initial, ss_ending, verbose=verbose, linear_solver=linear_solver, inner=inner, α=α)
-        x = x - y
-        i += 1
-        if verbose:
-            print(f"Iteration: {i}, norm(y): {np.linalg.norm(y)}")
+    try:
+        while ε < np.linalg.norm(y) and i < 100:
+            y = y_Iteration(J̅, x, y, exog_paths, mod, ss_initial, ss_ending, verbose=verbose, linear_solver=linear_solver, inner=inner, α=α)
+            x = x - y
+            i += 1
+            if verbose:
+                print(f"Iteration: {i}, norm(y): {np.linalg.norm(y)}")
+    finally:
+        release_linear_solver()         # (the factorisations of J̅ live for one solve, not for the life of the process)
     NewtonRaphsonHANK.iterations = i - 1
     return x

@@ -80,6 +80,7 @@ struct XWork {
     int *srcB = nullptr, *srcF = nullptr;     // [P][Sact] source-member ranges of the tangent sweeps at the recorded primal
     int2 *unitsF = nullptr;                   // [P][Sact][XUCAP] the forward sweeps' work units (k_xunits_fwd)
     int *unit_overflow = nullptr;             // set by k_xunits_fwd when a member has more units than XUCAP
+    int ucap = 64;                            // dev knob HANK_XUCAP (read once, at hank_create): a smaller budget, to exercise the overflow path
     bool rng_valid = false;                   // srcF / unitsF belong to the recorded lottery
     bool neigh = true;                        // dev knob HANK_XNEIGH=0 (read once, at hank_create): every period waits for every member
     bool syncwave = true;                     // dev knob HANK_XSYNCWAVE=0 (read once, at hank_create): wave 0 polls instead of an extra wave
@@ -571,6 +572,7 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.unit_overflow, 1));
     HIPC(ctx, hipMemset(X.unit_overflow, 0, sizeof(int)));
     if (const char *ng = getenv("HANK_XNEIGH")) X.neigh = atoi(ng) != 0;
+    if (const char *uc = getenv("HANK_XUCAP")) X.ucap = std::min(XUCAP, std::max(1, atoi(uc)));
     {   // the bound on every wait inside a persistent sweep, in 100 MHz ticks (read once, here)
         double ms = 20.0;
         if (const char *wm = getenv("HANK_XWAIT_MS")) ms = atof(wm);
@@ -675,7 +677,7 @@ static void x_launch_fwd(const XWork &X, int D, bool val, dim3 grd, dim3 blk, si
 static void x_ensure_rng(hank_ctx *ctx) {
     XWork &X = ctx->xw;
     if (X.rng_valid) return;
-    hipLaunchKernelGGL(k_xunits_fwd, dim3((unsigned)ctx->c.P, (unsigned)X.Sact), dim3(256), 0, ctx->stream, ctx->c, ctx->R, X.Sact, X.srcF, X.unitsF, X.unit_overflow);
+    hipLaunchKernelGGL(k_xunits_fwd, dim3((unsigned)ctx->c.P, (unsigned)X.Sact), dim3(256), 0, ctx->stream, ctx->c, ctx->R, X.Sact, X.srcF, X.unitsF, X.unit_overflow, X.ucap);
     X.rng_valid = true;
 }
 
@@ -740,7 +742,7 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullp
     if (!skip_fwd) {
         XSweepFwdArgs fa{};
         fa.c = c; fa.R = ctx->R; fa.sy = X.sync + 1; fa.st = X.st_D; fa.D0 = ctx->d_ss_D; fa.groups = 1; fa.Dvirt = X.Dvirt; fa.aggpart = X.aggpart;
-        fa.src = X.srcF; fa.units = X.unitsF; fa.all_members = X.neigh ? 0 : 1;
+        fa.src = X.srcF; fa.units = X.unitsF; fa.overflow = X.unit_overflow; fa.all_members = X.neigh ? 0 : 1;
         x_launch_fwd(X, 0, true, grd, blkf, x_lds_fwd(c, 1), s, fa);
     }
     HIPC(ctx, hipEventRecord(ctx->ev[2], s));
@@ -796,7 +798,7 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_bac
     ab.src = neigh ? X.srcB : nullptr;
     ab.stall = X.fault == 3 ? 1 : 0;
     XSweepFwdArgs fa{};
-    fa.c = c; fa.R = ctx->R; fa.st = X.st_dD; fa.daggpart = w->daggpart; fa.src = X.srcF; fa.units = X.unitsF; fa.all_members = neigh ? 0 : 1;
+    fa.c = c; fa.R = ctx->R; fa.st = X.st_dD; fa.daggpart = w->daggpart; fa.src = X.srcF; fa.units = X.unitsF; fa.overflow = X.unit_overflow; fa.all_members = neigh ? 0 : 1;
     HIPC(ctx, hipEventRecord(ctx->ev[3], s));
     for (int p = 0; p < np && !skip_back; p++) {
         const XPass &ps = w->passes[p];
@@ -1343,10 +1345,13 @@ static bool use_x_fused(const hank_ctx *ctx, int N) {
 
 // a sweep could not form its groups (or timed out): this context continues on the per-period launches
 static int to_launch_schedule(hank_ctx *ctx) {
+    ctx->primal_done = false;
+    if (!ctx->g_pback) {                    // (a context that has only run persistent sweeps has never captured them)
+        const int rc = build_primal_graphs(ctx);
+        if (rc != HANK_OK) return rc;       // the schedule is left as it was: the next call reports the sweep's failure again, not a null graph
+    }
     ctx->schedule = 0;
     ctx->stats[4]++;
-    ctx->primal_done = false;
-    if (!ctx->g_pback) return build_primal_graphs(ctx);
     return HANK_OK;
 }
 static bool x_fallback_allowed(const hank_ctx *ctx) { return !ctx->forced_xcd; }      // a schedule forced at hank_create fails loudly instead
@@ -1372,7 +1377,9 @@ int hank_check(hank_ctx *ctx) {
     if (rc == HANK_ERR_SWEEP && ctx->schedule >= 1 && x_fallback_allowed(ctx)) {
         char keep[sizeof(ctx->errmsg)];
         memcpy(keep, ctx->errmsg, sizeof(keep));
-        (void)to_launch_schedule(ctx);
+        const int rc2 = to_launch_schedule(ctx);
+        if (rc2 != HANK_OK) return rc2;     // the launches' graphs could not be built either: THAT is what the caller has to see (the
+                                            // message names it); the context stays unusable until a later call succeeds in building them
         memcpy(ctx->errmsg, keep, sizeof(keep));
     }
     return rc;

@@ -1155,6 +1155,7 @@ struct XSweepFwdArgs {
     double *aggpart;            // VAL: [P][members][2]
     double *daggpart;           // D > 0: [P][members][2*XG*D]
     const int *src;             // [P][members] lo | hi << 8 | (some column clamped) << 16 | (member 0 records row 0's full mass) << 17 | units << 18
+    const int *overflow;        // k_xunits_fwd's flag: a member's walk did not fit XUCAP units — nothing is computed from a truncated list
     const int2 *units;          // [P][members][XUCAP] {e | ja << 4 | cnt << 16, ta | tb << 8 | nv << 16}
     int all_members;            // dev knob: every period waits for every member
 };
@@ -1184,6 +1185,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     int *closh = reinterpret_cast<int *>(aggsh + (size_t)ne * 64 * NAP);           // [P][ne]: the clamped-prefix lengths (a cold uniform load per period otherwise)
     int *srcsh = closh + (size_t)P * ne;                // [P]
     int *ctl = srcsh + P;
+    if (*A.overflow) return;                            // (every workgroup of the launch reads the same word: written by a kernel that ran before it)
     const XGroup g = xgroup_join(A.sy, ctl);
     if (!g.ok) return;
     const int x = g.x, cW = g.c;
@@ -1529,7 +1531,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
 // column; unit u goes to wave u mod n_e. Per (period, member) also: the members its sources belong to (lo | hi << 8), whether
 // some column is clamped in the period (<< 16: the virtual rows hold mass in the next one), whether member 0 needs every
 // member's virtual row for the record of row 0 (<< 17), and the unit count (<< 18).
-__global__ void k_xunits_fwd(Consts c, Record R, int Sact, int *src, int2 *units, int *overflow) {
+__global__ void k_xunits_fwd(Consts c, Record R, int Sact, int *src, int2 *units, int *overflow, int ucap) {
     __shared__ int2 su[16][XUCAP];
     __shared__ int scnt[16], slo, shi, sany0;
     __shared__ int sst[16][XRW + 3];                    // start[r0-1 .. r0+nrows] of every column: the walk below is serial per column,
@@ -1616,7 +1618,7 @@ __global__ void k_xunits_fwd(Consts c, Record R, int Sact, int *src, int2 *units
         for (int e = 0; e < ne; e++) {
             if (sclo[e] > 0) anyclo = 1; else anyopen = 1;
         }
-        if (tot > XUCAP) { atomicExch(overflow, 1); tot = XUCAP; }
+        if (tot > ucap) { atomicExch(overflow, 1); tot = min(tot, XUCAP); }      // (ucap = XUCAP but for the dev knob HANK_XUCAP)
         int ml = min(slo, m), mh = max(shi, m);
         if (sany0) { ml = 0; mh = Sact - 1; }           // the units with virtual lanes read every member's virtual row
         const int allv = (m == 0 && vnz && anyopen) ? 1 : 0;

@@ -140,3 +140,53 @@ def test_a_wait_that_really_times_out_is_bounded_in_time(hank, monkeypatch):
     hb.close()
     monkeypatch.delenv("HANK_XWAIT_MS", raising=False)
     ref.close()
+
+
+def test_work_unit_overflow_is_served_by_the_launches(hank, monkeypatch):
+    """A member whose walk over its sources needs more work units than the budget (XUCAP = 64 per member and period; a savings
+    policy that is flat in index space) — exercised through the dev knob HANK_XUCAP=3, which lowers the budget k_xunits_fwd
+    checks against. The forward sweeps leave BEFORE computing anything from a truncated unit list (k_xfwd reads the flag at entry);
+    the host-pointer entries return the launches' numbers and the context stays on them, the asynchronous entries report the
+    overflow once at hank_check, a forced schedule fails loudly."""
+    m, ss, _ = ks_setup(130, 3, 20)
+    P = 19
+    x, _ = ks_paths(m, ss, "x1", 0.05)
+    y = np.random.default_rng(2).standard_normal((2, P, 5))
+    ref = _block(hank, m, monkeypatch, sched="launch")
+    ref.set_boundary(ss.value, ss.D)
+    agg0 = ref.primal(x[2:4]); d0 = ref.jvp(y); both0 = ref.primal_jvp(x[2:4], y)
+    monkeypatch.setenv("HANK_XUCAP", "3")
+    hb = _block(hank, m, monkeypatch)
+    hb.set_boundary(ss.value, ss.D)
+    assert hb.stats()["schedule"] == 2
+    assert np.array_equal(hb.primal(x[2:4]), agg0)
+    st = hb.stats()
+    assert st["fallbacks"] == 1 and st["schedule"] == 0
+    assert np.array_equal(hb.jvp(y), d0)
+    hb.close()
+    hb = _block(hank, m, monkeypatch)
+    hb.set_boundary(ss.value, ss.D)
+    a, d = hb.primal_jvp(x[2:4], y)
+    assert np.array_equal(a, both0[0]) and np.array_equal(d, both0[1]) and hb.stats()["fallbacks"] == 1
+    hb.close()
+    # asynchronous entry: reported once at hank_check, then the launches serve the context
+    dev = torch.device("cuda", 0)
+    d_x = torch.from_numpy(np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()).to(dev)
+    d_agg = torch.empty(P, dtype=torch.float64, device=dev)
+    hb = _block(hank, m, monkeypatch)
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
+    with pytest.raises(hank.HankHIPError, match="work units") as ei:
+        hb.check()
+    assert ei.value.code == hank.hip.HANK_ERR_SWEEP
+    hb.primal_dev(d_x.data_ptr(), d_agg.data_ptr())
+    hb.check()
+    assert hb.stats()["schedule"] == 0 and np.array_equal(d_agg.cpu().numpy(), agg0)
+    hb.close()
+    hb = _block(hank, m, monkeypatch, sched="xcd")
+    hb.set_boundary(ss.value, ss.D)
+    with pytest.raises(hank.HankHIPError, match="work units"):
+        hb.primal(x[2:4])
+    hb.close()
+    monkeypatch.delenv("HANK_XUCAP", raising=False)
+    ref.close()

@@ -115,6 +115,25 @@ def test_solve_above_2000_unknowns_keeps_the_persistent_schedule(hank):
     assert st["fallbacks"] == 0 and st["schedule"] != 0, st
 
 
+def test_device_and_host_linear_solvers_reach_the_same_path(hank):
+    """`linear_solver="device"` (J̅⁻¹ formed once on the model's GPU, one GEMV per inner iteration) against `"lu"` (host LU) on a
+    model large enough for the device branch (7 x 299 unknowns): the same converged path, and the factorisations are released when
+    NewtonRaphsonHANK returns (they used to live for the life of the process, on torch's current device)."""
+    from examples.solve_hank import build
+    import hank_amd as h
+    from hank_amd import NewtonRaphson as nr
+    m, ss = build(130, 3, 300)
+    P = m.compspec.T - 1
+    ei = {"ei": 0.0025 * 0.6 ** np.arange(P)}
+    keys = h.vars_of_type(m, "endogenous")
+    x0 = np.tile(np.array([ss.vars[k] for k in keys]), P)
+    J = h.getSteadyStateJacobian(ss, m)
+    xs = {ls: h.NewtonRaphsonHANK(x0, J, ei, m, ss, ss, linear_solver=ls) for ls in ("lu", "device")}
+    assert not nr._INV_CACHE and not nr._LU_CACHE
+    close(xs["device"], xs["lu"], rel=1e-8)
+    assert np.linalg.norm(h.LinearizedFunction(xs["device"], ei, m, ss, ss).Fx) < 1e-8
+
+
 def test_residual_layer_linearised_once_equals_the_dual_evaluation(hank):
     """LinearizedFunction.jvp through the sparse maps dR/dx, dR/dagg built once per x (one Dual evaluation of the compiled
     equations, colours = padded column mod (1 + max_lag + max_lead)) against the reference's way — the equations re-evaluated
