@@ -983,6 +983,7 @@ static int w_run_tangent(hank_ctx *ctx, WTan *w, const double *d_dxhh) {
     auto off = [&](const void *p) { return (unsigned)((const char *)p - ctx->rec_slab); };
     const Record &R = ctx->R;
     a.o_s = off(R.s); a.o_kc = off(R.kc); a.o_u = off(R.u); a.o_v = off(R.v); a.ibw = ctx->d_ibw;
+    a.nrank = std::max(1, std::min(ctx->num_cus / 8, w->N / 8));       // workgroups per XCD of the backward launch (hank_wide.h: L2 warming)
     a.o_lwg = off(R.lwg); a.o_start = off(R.start); a.o_D = off(R.Dseq); a.o_pol = off(R.pol);
     if (!ctx->wprep_valid) {                // once per recorded primal
         const size_t npt = (size_t)c.P * c.G;

@@ -134,6 +134,13 @@ __device__ __forceinline__ void wide_st64_nt(double v, __amdgpu_buffer_rsrc_t rs
 }
 
 // dev build only (make stamp): s_memtime of wave 0 / lane 0 of workgroup 0 at fixed points of periods [100, 104)
+// dev timing builds (wrong numbers): HANK_WIDE_TIMING_L2 confines the record to two periods (every line an L2 hit: what the HBM
+// latency of the record stream costs)
+#ifdef HANK_WIDE_TIMING_L2
+#define WIDE_TPER(t) ((t) & 1)
+#else
+#define WIDE_TPER(t) (t)
+#endif
 #ifdef HANK_XSTAMP
 __device__ unsigned long long g_wstamps[2][4][64];
 #define WSTAMP(sw, per, i)                                                                                          \
@@ -157,6 +164,7 @@ struct WideArgs {
     const void *rec;
     unsigned o_s, o_kc, o_u, o_v, o_lwg, o_start, o_D, o_pol;
     const int *ibw;         // [P][G] bracket | (A == B == 0) << 31 (k_wide_prep)
+    int nrank;              // backward: the workgroups that share an XCD's L2 split the next period's record lines `nrank` ways (L2 warming)
 };
 
 // dynamic LDS of the two kernels: the exchanged column holds a slot for every row a thread may own (R * WIDE_MAXT >= n_a)
@@ -253,11 +261,42 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
             wide_ld2d<0>(rs, rw.o8[j], A.o_v + so * 8, S.cv[2 * j], S.cv[2 * j + 1]);
         }
     };
+    // L2 WARMING. Every workgroup streams the same record, a period behind the same clock: whichever workgroup of an XCD asks for a
+    // line first waits for HBM (2-3 us), the others find it in that XCD's L2 — and with the loads of a column issued ONE column
+    // (~1 us) ahead the front runner stalls at every column and everybody runs at its pace (stamps, profiles/r05b_wide_stamps256.log:
+    // ~2 000 of a column's ~4 500 clocks; with the record confined to two periods, every load an L2 hit, the sweep takes 5.2 ms
+    // instead of 7.1). Vector-memory loads return in order, so a wave cannot keep a miss in flight behind the data it needs next —
+    // except where the period has slack of its own: the mixing at its top. There every workgroup asks for ONE dword of every
+    // nrank-th 128-byte line of the PREVIOUS period's arrays (the next one in sweep order: its share of the XCD's 32 workgroups,
+    // ~150 of 4 800 lines, one instruction per descriptor), a whole period before anybody reads them: HBM -> L2 happens once per
+    // XCD, off everybody's critical path. The share is blockIdx-derived (workgroups are dealt to the XCDs round-robin): an
+    // assumption about SPEED only — a line nobody warmed is an ordinary miss.
+    const int tch_line = ((int)(blockIdx.x >> 3) % A.nrank + A.nrank * tid) * 128;
+    const int tch_n8 = G * 8, tch_n4 = G * 4;
+    constexpr int TCH_ARR = DIET ? 3 : 4;
+    int tch_arr = 0, tch_off = tch_line;
+#pragma unroll
+    for (int k = 1; k < TCH_ARR; k++)
+        if (tch_off >= tch_n8) { tch_off -= tch_n8; tch_arr = k; }
+    // (branch-free: a lane without a line asks for an offset beyond the descriptor's range — no memory access, the answer is zero;
+    // a divergent branch or a per-lane scalar offset around the load costs the compiler its count of the loads in flight, and
+    // every wait behind it becomes vmcnt(0): the miss this is about would be waited for)
+    const int tch_v8 = tch_off < tch_n8 ? (int)(tch_arr == 0 ? A.o_s : tch_arr == 1 ? A.o_u : tch_arr == 2 ? A.o_v : A.o_kc) + tch_off : (int)0x80000000;
+    const int tch_v4 = tch_line < tch_n4 ? tch_line : (int)0x80000000;
+    unsigned tch_j8 = 0, tch_j4 = 0;
     __syncthreads();
-    { const int so = (P - 1) * G; load_X(so); load_Y1(so); load_Y2(so); }
+    { const int so = WIDE_TPER(P - 1) * G; load_X(so); load_Y1(so); load_Y2(so); }
     int pb = 0;
     for (int t = P - 1; t >= 0; t--) {
         WSTAMP(0, t, 0);
+#ifndef HANK_WIDE_NO_TOUCH
+        asm volatile("" :: "v"(tch_j8), "v"(tch_j4));       // (last period's two: long landed)
+        {
+            const int tb = WIDE_TPER(t > 0 ? t - 1 : 0) * G;
+            tch_j8 = __builtin_amdgcn_raw_buffer_load_b32(rs, tch_v8, tb * 8, 0);
+            tch_j4 = __builtin_amdgcn_raw_buffer_load_b32(rs_w, tch_v4, tb * 4, 0);
+        }
+#endif
         // (uniform over the workgroup: scalar registers)
         const double rho = wide_uniform(uni[8 * t]), opr = wide_uniform(uni[8 * t + 1]), w = wide_uniform(uni[8 * t + 2]), tr = wide_uniform(uni[8 * t + 3]);
         const double dr = wide_uniform(uni[8 * t + 4]), dw = wide_uniform(uni[8 * t + 5]), dtr = wide_uniform(uni[8 * t + 6]);
@@ -270,7 +309,7 @@ __global__ void __launch_bounds__(MAXT) k_wide_back(WideArgs A, WMat<NE> M) {
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const int last = e + 1 == NE;
-            const int son = (last ? (t > 0 ? t - 1 : 0) : t) * G + (last ? 0 : e + 1) * na + zt;      // the next column (of the next period behind the last)
+            const int son = WIDE_TPER(last ? (t > 0 ? t - 1 : 0) : t) * G + (last ? 0 : e + 1) * na + zt;      // the next column (of the next period behind the last)
             const double ze = M.z[e], wz = w * ze + tr, zd = ze * dw + dtr;
             double2 *const col = buf + pb * CS;
             double ds[R];
@@ -374,7 +413,7 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
 #pragma unroll
     for (int j = 0; j < R / 2; j++) so4[j] = (rw.ok[2 * j] ? max(rw.row[2 * j] - 1, 0) : 0) * 4;
     auto load_src = [&](int t, int e, int zt) {
-        const int pt = e * na + zt, so = t * G + pt;
+        const int pt = e * na + zt, so = WIDE_TPER(t) * G + pt;
         const __amdgpu_buffer_rsrc_t rs_dp = wide_rsrc(A.dpol + ((size_t)t * A.Ntot + n) * (size_t)G);
 #pragma unroll
         for (int j = 0; j < R / 2; j++) {
@@ -386,7 +425,7 @@ __global__ void __launch_bounds__(MAXT) k_wide_fwd(WideArgs A, WMat<NE> M) {
         }
     };
     auto load_seg = [&](int t, int e, int zt) {
-        const int so = ((t * NE + e) * (na + 1) + zt) * 4;
+        const int so = ((WIDE_TPER(t) * NE + e) * (na + 1) + zt) * 4;
 #pragma unroll
         for (int j = 0; j < R / 2; j++) {
             const wv4u v = wide_ld128(rs, so4[j], A.o_start + so);
