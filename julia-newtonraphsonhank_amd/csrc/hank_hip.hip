@@ -138,7 +138,7 @@ struct hank_ctx {
     struct { double *dpT = nullptr, *iota = nullptr, *E = nullptr, *Cp = nullptr, *F = nullptr, *Dv = nullptr; int N = 0; } fn;   // hank_fake_news workspace
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     // on-chip wide sweeps: 0 = never, 1 = auto (batches of at least wide_min directions), 2 = every batch (HANK_SCHEDULE=wide: tests)
-    int wide_mode = 0, wide_min = 152, num_cus = 256, wide_r = 4;     // wide_r: rows per thread of the wide kernels (dev knob HANK_WIDE_R=2|4 at hank_create)
+    int wide_mode = 0, wide_min = 152, num_cus = 256, wide_r = 2;     // wide_r: rows per thread of the wide kernels (2: 1024-thread workgroups, 4 waves per SIMD — since the L2 warming of round 5 the faster geometry for both sweeps, 5.16 / 6.80 ms against 5.30 / 7.10 at N=256; dev knob HANK_WIDE_R=2|4 at hank_create)
     size_t lds_max = 65536;
     char *rec_slab = nullptr;      // the record's ONE allocation
     size_t rec_bytes = 0;
@@ -1141,7 +1141,7 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     }
     // on-chip wide sweeps (hank_wide.h): "auto" sends tangent batches of at least wide_min directions to them (measured crossover,
     // DESIGN.md section 4); a forced schedule (launch | xcd) keeps its one implementation; HANK_SCHEDULE=wide sends every batch (tests)
-    if (const char *wr = getenv("HANK_WIDE_R")) ctx->wide_r = atoi(wr) == 2 ? 2 : 4;
+    if (const char *wr = getenv("HANK_WIDE_R")) ctx->wide_r = atoi(wr) == 4 ? 4 : 2;
     ctx->wide_mode = (w_supported(ctx) && !(se && (strcmp(se, "launch") == 0 || strcmp(se, "xcd") == 0))) ? 1 : 0;
     if (se && strcmp(se, "wide") == 0) {
         if (!w_supported(ctx))

@@ -48,13 +48,54 @@ __device__ inline void set_err(int *err, int code, int t, int e, int j) {
 
 __device__ inline bool pow_domain_error(double v, double y) { return (v < 0.0) && (y != floor(y)); }
 
-// x^y with the exponents CRRA utility produces most often taken through correctly rounded
-// division / square root (γ = 2: y = -1/2 and y = -2; γ = 1: y = -1) — a generic fp64 pow is a few
-// hundred VALU instructions on the primal sweep's critical path. Same value as pow() to an ulp.
+// Reciprocal and reciprocal square root of the primal EGM step: the hardware estimate (v_rcp_f64 / v_rsq_f64) and two Newton
+// steps, without the div_scale / div_fmas / div_fixup wrapper of an IEEE division (~18 instructions) or the scaling of an IEEE
+// square root. The operands — a marginal value, a consumption level, the distance of two sorted knots — are positive, finite and
+// far from the denormal range wherever the step does not report ERR_KNOTS / ERR_DOMAIN anyway (zero or negative arguments give
+// inf / NaN as the IEEE forms do); the results are within an ulp or two of the correctly rounded ones (oracle tolerance: 1e-10).
+// A row of the Dual pass's backward half does four divisions and two roots: ~110 of its ~500 instructions per wave and period,
+// on the critical path of a SIMD's three waves (the staircase at the tile barrier). EVERY primal
+// kernel takes its quotients and roots from here (egm_X / egm_Y / diet_v are shared), so k_egm_step, k_xprimal_back, k_xdual_back
+// and k_xvfi still agree with each other bit for bit.
+#ifndef HANK_IEEE_DIV
+#define HANK_IEEE_DIV 0     // dev knob: 1 = the IEEE forms (A/B, profiles/r05c_fast_div.log)
+#endif
+__device__ __forceinline__ double fast_rcp(double x) {
+#if HANK_IEEE_DIV
+    return 1.0 / x;
+#else
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+#endif
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+#if HANK_IEEE_DIV
+    return 1.0 / sqrt(x);
+#else
+    double y = __builtin_amdgcn_rsq(x);
+    y = __builtin_fma(y * 0.5, __builtin_fma(-(x * y), y, 1.0), y);
+    y = __builtin_fma(y * 0.5, __builtin_fma(-(x * y), y, 1.0), y);
+    return y;
+#endif
+}
+__device__ __forceinline__ double fast_sqrt(double x) {     // x rsqrt(x), one correction of the product
+#if HANK_IEEE_DIV
+    return sqrt(x);
+#else
+    const double y = fast_rsqrt(x), g = x * y;
+    return __builtin_fma(y * 0.5, __builtin_fma(-g, g, x), g);
+#endif
+}
+
+// x^y with the exponents CRRA utility produces most often taken through a reciprocal / reciprocal square root
+// (gamma = 2: y = -1/2 and y = -2; gamma = 1: y = -1) — a generic fp64 pow is a few
+// hundred VALU instructions on the primal sweep's critical path. Same value as pow() to an ulp or two.
 __device__ inline double pow_crra(double x, double y) {
-    if (y == -0.5) return 1.0 / sqrt(x);
-    if (y == -2.0) return 1.0 / (x * x);
-    if (y == -1.0) return 1.0 / x;
+    if (y == -0.5) return fast_rsqrt(x);
+    if (y == -2.0) return fast_rcp(x * x);
+    if (y == -1.0) return fast_rcp(x);
     return pow(x, y);
 }
 
@@ -162,7 +203,7 @@ __device__ __forceinline__ double diet_kc(const Consts &c, double s, double rho,
     return c.gamma == 2.0 ? k * (cm * cm * cm) : k * (cm * cm);
 }
 __device__ __forceinline__ double diet_v(const Consts &c, double u, double opr) {
-    return c.gamma == 2.0 ? opr * (-2.0 * (u * sqrt(u))) : opr * (-(u * u));
+    return c.gamma == 2.0 ? opr * (-2.0 * (u * fast_sqrt(u))) : opr * (-(u * u));
 }
 
 // household inputs of period t: xhh[n_hh*t + k]; the lump-sum transfer is 0 for families without one
@@ -254,11 +295,11 @@ __device__ inline YOut egm_Y(const Consts &c, const KNOTS sc, int a, int e, doub
         }
         i = lo < 0 ? 0 : (lo > n - 2 ? n - 2 : lo);
         const double si = have ? vlo : sc[i], sj = have ? vhi : sc[i + 1];
-        const double h = sj - si;
-        const double f = (x - si) / h;
+        const double h = sj - si, rh = fast_rcp(h);      // (one reciprocal serves both quotients)
+        const double f = (x - si) * rh;
         const double ai = c.a[i], aj = c.a[i + 1];
         g = (1.0 - f) * ai + f * aj;
-        const double sl = (aj - ai) / h;
+        const double sl = (aj - ai) * rh;
         A = -sl * (1.0 - f);
         B = -sl * f;
     }

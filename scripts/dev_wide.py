@@ -75,11 +75,11 @@ def timing(Ns, n_a=2000, n_e=11, T=300):
     dev = torch.device("cuda", 0)
     d_x = torch.from_numpy(np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()).to(dev)
     res = {}
-    variants = (("wide", {}), ("wide", {"HANK_WIDE_R": 2}), ("auto", {"HANK_WIDE_MIN": 100000}))
+    variants = (("wide", {}), ("wide", {"HANK_WIDE_R": 4}), ("auto", {"HANK_WIDE_MIN": 100000}))
     if os.environ.get("DEV_WIDE_ONLY"):
         variants = variants[:2]
     for sched, env in variants:
-        sched_name = sched + ("_r2" if env.get("HANK_WIDE_R") == 2 else "")
+        sched_name = sched + ("_r4" if env.get("HANK_WIDE_R") == 4 else "")
         hb = block(m, sched, **env)
         hb.set_boundary(ss.value, ss.D)
         for N in Ns:
@@ -107,7 +107,7 @@ def timing(Ns, n_a=2000, n_e=11, T=300):
                   + " ".join(f"{k2}={v['ms']:.2f}" for k2, v in tm.items() if v['ms'] > 0) + f" | {hb.info()['last_tangent_family_name']}", flush=True)
         hb.close()
     for N in Ns:
-        for other in ("wide_r2", "auto"):
+        for other in ("wide_r4", "auto"):
             if (other, N) in res:
                 print(f"   N={N}: wide vs {other} dagg rel {rel(res[('wide', N)], res[(other, N)]):.2e}")
 
