@@ -143,6 +143,7 @@ struct hank_ctx {
     char *rec_slab = nullptr;      // the record's ONE allocation
     size_t rec_bytes = 0;
     int *d_ibw = nullptr;          // the wide backward sweep's bracket record (k_wide_prep), valid for the recorded primal or not
+    bool seg_valid = true;          // the record's per-target segment records match its lottery (k_lottery writes them except in the persistent Dual pass)
     bool wprep_valid = false;
     std::list<WTan> wtans;         // most recently used first
     WTan *wcur = nullptr;
@@ -258,7 +259,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
                        ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1, (const int *)nullptr);
     for (int t = P - 1; t >= 0; t--)
         hipLaunchKernelGGL(k_egm_step, grd, blk, lds, s, c, ctx->R, ctx->d_xhh, t, ctx->d_err);
-    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, P * c.n_e, ctx->d_err);
+    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, P * c.n_e, ctx->d_err, 1);
     int rc = end_capture(ctx, &ctx->g_pback);
     if (rc) return rc;
     // forward
@@ -369,7 +370,7 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int which) {
             cur ^= 1;
         }
     }
-    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
+    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err, 1);
     rc = end_capture(ctx, &w.g_fback);
     if (rc) return rc;
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -681,6 +682,13 @@ static void x_ensure_rng(hank_ctx *ctx) {
     X.rng_valid = true;
 }
 
+static int ensure_seg(hank_ctx *ctx) {       // before a reader of R.seg (launch-family forward tangent sweeps, hank_fake_news)
+    if (ctx->seg_valid) return HANK_OK;
+    hipLaunchKernelGGL(k_seg_build, dim3((unsigned)(ctx->c.P * ctx->c.n_e)), dim3(256), 0, ctx->stream, ctx->c, ctx->R, ctx->c.P * ctx->c.n_e);
+    HIPC(ctx, hipGetLastError());
+    ctx->seg_valid = true;
+    return HANK_OK;
+}
 static int x_serialize_begin(hank_ctx *ctx) {
     std::lock_guard<std::mutex> lk(g_xmutex);
     if (g_xlast[ctx->device & 63]) HIPC(ctx, hipStreamWaitEvent(ctx->stream, g_xlast[ctx->device & 63], 0));
@@ -706,18 +714,20 @@ static int x_sync_reset(hank_ctx *ctx, XSync *base, int count, int where) {     
 // skip_fwd: the distribution sweep travels with the tangents' forward sweep instead (k_xfwd<D, true>, x_run_tangent(.., val))
 // dual: the backward sweep carries the partials of this ONE-pass batch too (k_xdual_back; implies skip_fwd — the caller follows
 // with x_run_tangent(.., val, skip_back))
-static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullptr) {
+static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullptr, bool pro_done = false) {      // pro_done: k_xdual_prologue has run (x_dual)
     XWork &X = ctx->xw;
     const Consts &c = ctx->c;
     const size_t P = c.P;
     hipStream_t s = ctx->stream;
     int rc = x_serialize_begin(ctx);
     if (rc) return rc;
-    rc = x_sync_reset(ctx, X.sync, 2, 1);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
-    hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
-    if (dual) hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * dual->N + 255) / 256)), dim3(256), 0, s, dual->dxhh, c.n_hh, (int)P, dual->N, dual->dxr, dual->dxw, dual->dxt);
+    if (!pro_done) {
+        rc = x_sync_reset(ctx, X.sync, 2, 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
+        hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);
+        if (dual) hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * dual->N + 255) / 256)), dim3(256), 0, s, dual->dxhh, c.n_hh, (int)P, dual->N, dual->dxr, dual->dxw, dual->dxt);
+    }
     // + one wave that only runs the group barrier's poll, where the block has room (dev knob HANK_XSYNCWAVE=0: wave 0 polls)
     const bool fits = 64 * (c.n_e + 1) <= X.maxt && X.syncwave;
     const dim3 grd(X.grid), blk(fits ? 64 * (c.n_e + 1) : 64 * c.n_e), blkf = blk;
@@ -735,7 +745,9 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullp
     } else if (X.maxt == 768) hipLaunchKernelGGL((k_xprimal_back<768>), grd, blk, ldsb, s, ab);
     else hipLaunchKernelGGL((k_xprimal_back<1024>), grd, blk, ldsb, s, ab);
     HIPC(ctx, hipEventRecord(ctx->ev[1], s));
-    hipLaunchKernelGGL(k_lottery, dim3((unsigned)(P * c.n_e)), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err);
+    // (the Dual pass's forward half reads the lottery through its work units: the per-target segment records are built when somebody asks)
+    hipLaunchKernelGGL(k_lottery, dim3((unsigned)(P * c.n_e)), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err, dual ? 0 : 1);
+    ctx->seg_valid = !dual;
     X.rng_valid = false;
     x_ensure_rng(ctx);
     HIPC(ctx, hipEventRecord(ctx->ev[6], s));
@@ -770,7 +782,8 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullp
 // the N partials of `w` at the recorded primal: two persistent launches per pass of up to 8*dmax directions, every XCD a group
 // val: the first pass's forward sweep carries the value too (the Float64 distribution sweep of a Dual pass) and writes the record
 // skip_back: the backward sweep of this (one-pass) batch has run with the Float64 sweep (k_xdual_back, x_run_primal(.., dual))
-static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_back = false) {
+struct XOut { double *agg = nullptr, *dagg = nullptr; bool pro_done = false, done = false; };      // x_dual's merged launches: the caller's output buffers, and what has been done
+static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_back = false, XOut *xo = nullptr) {
     XWork &X = ctx->xw;
     const Consts &c = ctx->c;
     const size_t P = c.P;
@@ -779,8 +792,10 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_bac
     if (rc) return rc;
     const int np = (int)w->passes.size(), N = w->N;
     // sync blocks 0, 1 belong to the primal sweeps (their status is checked with this call's when both ran unchecked)
-    rc = x_sync_reset(ctx, X.sync + 2, 2 * np, 2);
-    if (rc) return rc;
+    if (!(xo && xo->pro_done)) {
+        rc = x_sync_reset(ctx, X.sync + 2, 2 * np, 2);
+        if (rc) return rc;
+    }
     if (!skip_back) hipLaunchKernelGGL(k_tan_in, dim3((unsigned)((P * N + 255) / 256)), dim3(256), 0, s, w->dxhh, c.n_hh, (int)P, N, w->dxr, w->dxw, w->dxt);
     if (!skip_back) hipLaunchKernelGGL(k_xrho, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, ctx->d_xhh, c.n_hh, (int)P, X.rho);     // (the primal may have been recorded by the launches)
     if (!X.src_valid && !skip_back) {      // once per recorded primal: which members each member's gathers read, period by period
@@ -816,13 +831,21 @@ static int x_run_tangent(hank_ctx *ctx, XTan *w, bool val = false, bool skip_bac
         const bool v = val && p == 0;
         if (v) { fa.D0 = ctx->d_ss_D; fa.Dvirt = X.Dvirt; fa.aggpart = X.aggpart; }
         x_launch_fwd(X, ps.D, v, grd, blkF, x_lds_fwd(c, ps.D + (v ? 1 : 0)), s, fa);
+        const int W = XG * ps.D;
+        if (v && np == 1 && xo) {               // the one-pass Dual pass: everything behind the sweep in ONE launch (k_xdual_epilogue)
+            HIPC(ctx, hipEventRecord(ctx->ev[5], s));
+            const int per = 2 * W + 2 + c.n_e;
+            hipLaunchKernelGGL(k_xdual_epilogue, dim3((unsigned)((P * per + 255) / 256)), dim3(256), 0, s, c, X.aggpart, w->daggpart, X.Sact, W, ps.n0, ps.N, N,
+                               ctx->d_agg_rm, ctx->d_agg, w->dagg_pass, w->dagg_cm, ctx->R.Dseq, X.Dvirt, xo->agg, xo->dagg);
+            xo->done = true;
+            break;
+        }
         if (v) {
             hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, 1), dim3(256), 0, s, X.aggpart, X.Sact, 2, ctx->d_agg_rm);
             hipLaunchKernelGGL(k_tan_out, dim3((unsigned)((2 * P + 255) / 256)), dim3(256), 0, s, ctx->d_agg_rm, (int)P, 2, ctx->d_agg);
             hipLaunchKernelGGL(k_xfix_D, dim3((unsigned)((P * c.n_e + 255) / 256)), dim3(256), 0, s, c, ctx->R.Dseq, X.Dvirt, X.Sact);
         }
         if (p == np - 1) HIPC(ctx, hipEventRecord(ctx->ev[5], s));
-        const int W = XG * ps.D;
         hipLaunchKernelGGL(k_reduce_parts, dim3((unsigned)P, (2 * W + 63) / 64), dim3(256), 0, s, w->daggpart, nb, 2 * W, w->dagg_pass);
         hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, 2 * W, 0, ps.n0, ps.N, w->dagg_cm);
         hipLaunchKernelGGL(k_xout, dim3((unsigned)((P * ps.N + 255) / 256)), dim3(256), 0, s, w->dagg_pass, (int)P, 2 * W, W, ps.n0, ps.N, w->dagg_cm + P * (size_t)N);
@@ -1281,7 +1304,7 @@ static int run_primal(hank_ctx *ctx, double *d_agg_out) {
     ctx->side_pending = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = true;
     ctx->ev_valid[4] = ctx->ev_valid[5] = false;
-    ctx->primal_done = true; w_new_primal(ctx);
+    ctx->primal_done = true; ctx->seg_valid = true; w_new_primal(ctx);
     ctx->xw.src_valid = false; ctx->xw.rng_valid = false;
     for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     return HANK_OK;
@@ -1309,16 +1332,31 @@ static int x_dual(hank_ctx *ctx, const double *xhh, const double *dxhh, hipMemcp
     const size_t P = ctx->c.P;
     // a Dual pass of one pass (N <= 8 groups x 4): value and partials together in BOTH sweeps (k_xdual_back, k_xfwd<D, true>)
     const bool fused_back = xhh && w->passes.size() == 1 && x_dual_back_fits(ctx, w->passes[0].D);
-    HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
+    XOut xo;
+    xo.agg = d_agg_out; xo.dagg = d_dagg_out;
+    XWork &X = ctx->xw;
+    if (fused_back && kind == hipMemcpyDeviceToDevice && !X.fault) {
+        // the one-pass Dual pass on device-resident inputs (what bench.py times): ONE launch in front of the sweeps instead of seven
+        // launches and copies (k_xdual_prologue); a fault-injection run (HANK_XFAULT) keeps the separate launches
+        rc = x_serialize_begin(ctx);        // (the sync blocks about to be zeroed may belong to a sweep still in flight on another stream)
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_xdual_prologue, dim3(64), dim3(256), 0, ctx->stream, xhh, ctx->d_xhh, dxhh, w->dxhh, ctx->c.n_hh, (int)P, N, X.rho, w->dxr, w->dxw, w->dxt,
+                           reinterpret_cast<xv4u *>(X.sync), sizeof(XSync) * 4 / sizeof(xv4u), ctx->d_err);
+        xo.pro_done = true;
+    } else {
+        HIPC(ctx, hipMemcpyAsync(w->dxhh, dxhh, sizeof(double) * ctx->c.n_hh * P * N, kind, ctx->stream));
+        if (xhh) HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, kind, ctx->stream));
+    }
     if (xhh) {
-        HIPC(ctx, hipMemcpyAsync(ctx->d_xhh, xhh, sizeof(double) * ctx->c.n_hh * P, kind, ctx->stream));
-        rc = x_run_primal(ctx, true, fused_back ? w : nullptr);        // the distribution sweep rides on the tangents' forward sweep (value + partials)
+        rc = x_run_primal(ctx, true, fused_back ? w : nullptr, xo.pro_done);        // the distribution sweep rides on the tangents' forward sweep (value + partials)
         if (rc) return rc;
     }
-    rc = x_run_tangent(ctx, w, xhh != nullptr, fused_back);
+    rc = x_run_tangent(ctx, w, xhh != nullptr, fused_back, &xo);
     if (rc) return rc;
-    if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
-    if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, w->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    if (!xo.done) {
+        if (d_agg_out) HIPC(ctx, hipMemcpyAsync(d_agg_out, ctx->d_agg, sizeof(double) * P, hipMemcpyDeviceToDevice, ctx->stream));
+        if (d_dagg_out) HIPC(ctx, hipMemcpyAsync(d_dagg_out, w->dagg_cm, sizeof(double) * P * N, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     return HANK_OK;
 }
 static bool use_x_primal(const hank_ctx *ctx) { return ctx->schedule >= 1; }
@@ -1431,6 +1469,7 @@ static int run_jvp(hank_ctx *ctx) {
     HIPC(ctx, hipGraphLaunch(w.g_back, ctx->stream));
     HIPC(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     HIPC(ctx, join_side(ctx));      // the tangent forward sweep needs D_t
+    { const int src = ensure_seg(ctx); if (src) return src; }
     HIPC(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
     HIPC(ctx, hipGraphLaunch(w.g_fwd, ctx->stream));
     HIPC(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
@@ -1518,7 +1557,7 @@ static int run_fused(hank_ctx *ctx) {
     HIPC(ctx, hipEventRecord(ctx->ev[10], ctx->stream));
     ctx->ev_valid[4] = ctx->ev_valid[5] = true;
     ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = ctx->ev_valid[3] = false;
-    ctx->primal_done = true; w_new_primal(ctx);
+    ctx->primal_done = true; ctx->seg_valid = true; w_new_primal(ctx);
     ctx->xw.src_valid = false; ctx->xw.rng_valid = false;
     for (TanWork &t : ctx->tws) t.valid = false; w_invalidate(ctx);
     w.valid = true;
@@ -1637,6 +1676,7 @@ int hank_fake_news(hank_ctx *ctx, double *F_out, double *Dv_out) {
             return fail(ctx, HANK_ERR_NOT_READY, "hank_fake_news: the recorded primal is not stationary (policy of period 1 and of period %d differ by %.3g): "
                         "it needs hank_primal at the steady state with the steady state as both boundaries", P, diff);
     }
+    { const int src = ensure_seg(ctx); if (src) return src; }
     // 1. n_hh backward tangent sweeps (one batch) seeded at the last period: every lag of the policy response
     int rc = ensure_tanwork(ctx, N);
     if (rc) return rc;
@@ -2165,7 +2205,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
     HIPC(ctx, hipMemcpyAsync(Dchk, D_io, sizeof(double) * G, hipMemcpyHostToDevice, s));
     HIPC(ctx, hipMemsetAsync(state, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
-    hipLaunchKernelGGL(k_lottery, dim3((unsigned)c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, R, c.n_e, ctx->d_err);
+    hipLaunchKernelGGL(k_lottery, dim3((unsigned)c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, R, c.n_e, ctx->d_err, 1);
     HIPC(ctx, hipGetLastError());
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
     int hstate[2] = {0, 0}, done = 0;

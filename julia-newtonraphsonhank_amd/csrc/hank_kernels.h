@@ -392,7 +392,7 @@ __global__ void k_egm_step(Consts c, Record R, const double *xhh, int t, int *er
 //              tangent — the borrowing-constraint mass point, summed separately (it is long);
 //   start[r] = max(clo, first source j with lo_j >= r): target row r receives w_j from the sources
 //              in [start[r-1], start[r]) and 1-w_j from those in [start[r], start[r+1]).
-__global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
+__global__ void k_lottery(Consts c, Record R, int ncols, int *err, int write_seg) {
     extern __shared__ int shlo[];
     __shared__ int sh_clo;
     const int col = blockIdx.x;
@@ -439,9 +439,21 @@ __global__ void k_lottery(Consts c, Record R, int ncols, int *err) {
     }
     __syncthreads();
     for (int r = threadIdx.x; r <= n; r += blockDim.x) st[r] = shst[r];
-    // per target row: its three segment bounds in one 16-byte record
+    // per target row: its three segment bounds in one 16-byte record — what the launch family's gather reads (and k_xstat, and
+    // k_fn_impulse); a third of this kernel's bytes, and the persistent Dual pass reads none of them: written there on demand
+    // (write_seg = 0, then k_seg_build before the first reader)
+    if (write_seg)
+        for (int r = threadIdx.x; r < n; r += blockDim.x)
+            R.seg[base + r] = make_int4(r > 0 ? shst[r - 1] : shst[r], shst[r], shst[r + 1], 0);
+}
+// the same records from the segment offsets k_lottery left (one block per column)
+__global__ void k_seg_build(Consts c, Record R, int ncols) {
+    const int col = blockIdx.x, n = c.n_a;
+    if (col >= ncols) return;
+    const int *st = R.start + (size_t)col * (n + 1);
+    const size_t base = (size_t)col * n;
     for (int r = threadIdx.x; r < n; r += blockDim.x)
-        R.seg[base + r] = make_int4(r > 0 ? shst[r - 1] : shst[r], shst[r], shst[r + 1], 0);
+        R.seg[base + r] = make_int4(r > 0 ? st[r - 1] : st[r], st[r], st[r + 1], 0);
 }
 
 // ---- distribution push-forward, one period (ForwardIteration.jl:95-99, :297-308) -------------

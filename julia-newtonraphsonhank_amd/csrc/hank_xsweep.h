@@ -1670,6 +1670,83 @@ __global__ void k_xout(const double *__restrict__ dagg, int P, int W, int src0, 
     out[(size_t)(n0 + n) * P + t] = dagg[(size_t)t * W + src0 + n];
 }
 
+// ---- the persistent Dual pass's small work in TWO launches (round 5) ---------------------------------------------------------
+// A one-pass Dual pass used to be wrapped in fifteen launches and copies of a few microseconds each (two input copies, two
+// memsets of the sync blocks, k_zero_i32, k_xrho, k_tan_in in front; k_reduce_parts, k_tan_out, k_xfix_D, k_reduce_parts, two
+// k_xout and two output copies behind): dependent launches on one stream cost ~3-5 us apiece, 0.07 ms of a 4.35 ms step.
+// k_xdual_prologue: inputs in (the caller's device buffers are read where they lie; the context keeps its copies), rho_t, the
+// per-direction input partials [P][N], the four sync blocks and the error word zeroed.
+__global__ void k_xdual_prologue(const double *__restrict__ xhh_src, double *__restrict__ xhh_dst, const double *__restrict__ dx_src, double *__restrict__ dx_dst,
+                                 int n_hh, int P, int N, double *__restrict__ rho, double *__restrict__ dxr, double *__restrict__ dxw, double *__restrict__ dxt,
+                                 xv4u *__restrict__ sync, size_t sync_q, int *__restrict__ err) {
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < sync_q; i += step) { xv4u z; z.x = z.y = z.z = z.w = 0u; sync[i] = z; }
+    if (i0 < 4) err[i0] = 0;
+    for (size_t t = i0; t < (size_t)P; t += step) {
+        rho[t] = 1.0 / (1.0 + xhh_src[(size_t)n_hh * t]);                   // (k_xrho's expression)
+        if (xhh_dst != xhh_src)
+            for (int k = 0; k < n_hh; k++) xhh_dst[(size_t)n_hh * t + k] = xhh_src[(size_t)n_hh * t + k];
+    }
+    for (size_t idx = i0; idx < (size_t)P * N; idx += step) {              // (k_tan_in)
+        const size_t t = idx / N, n = idx - t * N;
+        const size_t o = (size_t)n_hh * (t + (size_t)P * n);
+        const double a = dx_src[o], b = dx_src[o + 1], c2 = n_hh > 2 ? dx_src[o + 2] : 0.0;
+        dxr[idx] = a; dxw[idx] = b;
+        if (n_hh > 2) dxt[idx] = c2;
+        if (dx_dst != dx_src) { dx_dst[o] = a; dx_dst[o + 1] = b; if (n_hh > 2) dx_dst[o + 2] = c2; }
+    }
+}
+// the sum k_reduce_parts takes over nb row blocks, in its order (four strided groups of eight, then the groups)
+__device__ __forceinline__ double xreduce_parts_at(const double *__restrict__ parts, int nb, int N, int t, int n) {
+    const double *p = parts + (size_t)t * nb * N + n;
+    double sg[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        double s = 0.0;
+        int b = g;
+        for (; b + 28 < nb; b += 32) {
+            const double v0 = p[(size_t)b * N], v1 = p[(size_t)(b + 4) * N], v2 = p[(size_t)(b + 8) * N], v3 = p[(size_t)(b + 12) * N];
+            const double v4 = p[(size_t)(b + 16) * N], v5 = p[(size_t)(b + 20) * N], v6 = p[(size_t)(b + 24) * N], v7 = p[(size_t)(b + 28) * N];
+            s += ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+        }
+        for (; b < nb; b += 4) s += p[(size_t)b * N];
+        sg[g] = s;
+    }
+    return (sg[0] + sg[1]) + (sg[2] + sg[3]);
+}
+// k_xdual_epilogue: both aggregates of the value and of the pass's partials summed over the members (k_reduce_parts' order), laid
+// out as the entry points return them (k_tan_out, k_xout) — into the context's buffers AND the caller's —, and row 0 of every D_t
+// completed with the virtual rows' mass (k_xfix_D). One thread per (period, output).
+__global__ void k_xdual_epilogue(Consts c, const double *__restrict__ aggpart, const double *__restrict__ daggpart, int Sact, int W, int n0, int N, int Ntot,
+                                 double *__restrict__ agg_rm, double *__restrict__ agg_cm, double *__restrict__ dagg_pass, double *__restrict__ dagg_cm,
+                                 double *__restrict__ Dseq, const double *__restrict__ Dvirt, double *__restrict__ out_agg, double *__restrict__ out_dagg) {
+    const int P = c.P, per = 2 * W + 2 + c.n_e;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P * per) return;
+    const int t = idx / per, j = idx - t * per;
+    if (j < 2 * W) {
+        const double v = xreduce_parts_at(daggpart, Sact, 2 * W, t, j);
+        dagg_pass[(size_t)t * 2 * W + j] = v;
+        const int half = j >= W, n = j - half * W;
+        if (n < N) {
+            dagg_cm[(size_t)half * P * Ntot + (size_t)(n0 + n) * P + t] = v;
+            if (!half && out_dagg) out_dagg[(size_t)(n0 + n) * P + t] = v;
+        }
+    } else if (j < 2 * W + 2) {
+        const int k = j - 2 * W;
+        const double v = xreduce_parts_at(aggpart, Sact, 2, t, k);
+        agg_rm[(size_t)t * 2 + k] = v;
+        agg_cm[(size_t)k * P + t] = v;
+        if (k == 0 && out_agg) out_agg[t] = v;
+    } else {
+        const int e = j - 2 * W - 2;
+        const size_t q = (size_t)t * c.n_e + e, o = (size_t)(t + 1) * c.G + (size_t)e * c.n_a;
+        double sD = Dseq[o];
+        for (int m = 0; m < Sact; m++) sD += Dvirt[q * 64 + m];
+        Dseq[o] = sD;
+    }
+}
+
 // (G,P,N) col-major export of one pass's dpol [P][groups][G][D] into columns [n0, n0+N)
 __global__ void k_xexport_dpol(const double *dpol, int G, int P, int groups, int D, int n0, int N, double *out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
