@@ -138,7 +138,7 @@ struct hank_ctx {
     struct { double *dpT = nullptr, *iota = nullptr, *E = nullptr, *Cp = nullptr, *F = nullptr, *Dv = nullptr; int N = 0; } fn;   // hank_fake_news workspace
     XTan *xcur = nullptr;          // tangent buffers of the last xcd-schedule JVP
     // on-chip wide sweeps: 0 = never, 1 = auto (batches of at least wide_min directions), 2 = every batch (HANK_SCHEDULE=wide: tests)
-    int wide_mode = 0, wide_min = 152, num_cus = 256, wide_r = 2;     // wide_r: rows per thread of the wide kernels (2: 1024-thread workgroups, 4 waves per SIMD — since the L2 warming of round 5 the faster geometry for both sweeps, 5.16 / 6.80 ms against 5.30 / 7.10 at N=256; dev knob HANK_WIDE_R=2|4 at hank_create)
+    int wide_mode = 0, wide_min = 80, num_cus = 256, wide_r = 2;     // wide_r: rows per thread of the wide kernels (2: 1024-thread workgroups, 4 waves per SIMD — since the L2 warming of round 5 the faster geometry for both sweeps, 5.16 / 6.80 ms against 5.30 / 7.10 at N=256; dev knob HANK_WIDE_R=2|4 at hank_create)
     size_t lds_max = 65536;
     char *rec_slab = nullptr;      // the record's ONE allocation
     size_t rec_bytes = 0;
@@ -916,10 +916,11 @@ static bool w_supported(const hank_ctx *ctx) {
     return w_ne_instantiated(c.n_e) && c.n_a <= WIDE_CS && w_lds(ctx) <= ctx->lds_max &&
            ctx->rec_bytes < 0x7fffffffull && (size_t)c.G * sizeof(double) < 0x7fffffffull;
 }
-// auto: a workgroup (= a direction) per CU and round; a round costs what ~150 directions cost the per-period launches (measured at
-// 2000x11, T=300: 11.9 ms per round at a recorded primal — 13.9 with all 256 CUs busy — against 0.082 ms per direction), so the
-// batch goes to the wide sweeps when its last round is at least that full (N = 160, 256, 512: yes; N = 128, 300: no). wide_min
-// (HANK_WIDE_MIN) is that fill, in directions.
+// auto: a workgroup (= a direction) per CU and round; a round costs what ~80 directions cost the per-period launches (measured at
+// 2000x11, T=300, profiles/r05b_wide_crossover.log: 12.9 ms per round with the primal, 10.3 at a recorded primal, whatever its
+// fill; the launches 13.1 ms at N = 80, 14.0 at 128 and 23.5 from 144 on), so the batch goes to the wide sweeps when its last round
+// holds at least that many (before the L2 warming of k_wide_back a round cost 13.9 ms at a recorded primal and the crossover was 152).
+// wide_min (HANK_WIDE_MIN) is that fill, in directions.
 static bool use_wide(const hank_ctx *ctx, int N) {
     if (ctx->wide_mode == 2) return true;
     if (ctx->wide_mode != 1) return false;

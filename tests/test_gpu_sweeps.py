@@ -239,3 +239,27 @@ def test_default_schedule_runs_one_pass_dual_batches_on_the_persistent_dual_pass
     assert np.array_equal(aggw, agg1) and np.array_equal(daggw, dagg1)
     assert hb.stats()["fallbacks"] == 0
     ref.close()
+
+
+def test_segment_records_are_built_on_demand_behind_a_persistent_dual_pass(hank):
+    """The persistent Dual pass leaves the per-target segment records of the lottery (R.seg) unwritten — its forward half reads
+    work units — and whoever reads them next builds them first (k_seg_build): a launch-family batch (64 < N < the wide family's
+    crossover) at the primal a Dual pass recorded returns what it returns at the same primal recorded by hank_primal."""
+    m, ss, _ = ks_setup(500, 4, 300)
+    P = 299
+    x, _ = ks_paths(m, ss, "x1", 0.01)
+    rng = np.random.default_rng(5)
+    y32, y100 = rng.standard_normal((2, P, 32)), rng.standard_normal((2, P, 72))     # (72: between the persistent sweeps' 64 and the wide family's 80)
+    hb = hank.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    hb.primal(x[2:4])                                                           # the lottery writes the records itself
+    want = hb.jvp(y100)
+    assert hb.info()["last_tangent_family_name"] == "launch-per-period"
+    hb.primal_jvp(x[2:4] * 1.03, y32)                                           # other segments on record, written by k_lottery ...
+    hb.primal(x[2:4] * 1.03); hb.jvp(y100)                                      # ... and read by the launches
+    agg, dagg = hb.primal_jvp(x[2:4], y32)                                      # the persistent Dual pass at x: no records written
+    assert hb.last_timings()["tangent_forward"]["launches"] == 1
+    got = hb.jvp(y100)                                                          # the launches at that record: built on demand
+    assert hb.info()["last_tangent_family_name"] == "launch-per-period"
+    close(got, want, rel=1e-11)                                                 # (stale records — the other x's segments — are off by percents)
+    assert hb.stats()["fallbacks"] == 0

@@ -125,8 +125,9 @@ def test_wide_sweeps_one_asset_hank_family(hank):
 
 
 def test_default_schedule_sends_full_rounds_to_the_wide_sweeps(hank):
-    """auto: a batch whose last round fills the chip goes to the on-chip wide sweeps, a narrower one does not (measured crossover:
-    DESIGN.md section 4); a forced schedule keeps its one implementation."""
+    """auto: a batch of at least 80 directions goes to the on-chip wide sweeps (a round of them costs what 80 directions cost the
+    per-period launches since the L2 warming of round 5: DESIGN.md section 4), a narrower one does not; a forced schedule keeps its
+    one implementation."""
     m, ss, _ = ks_setup(50, 2, 20)
     P = 19
     x, _ = ks_paths(m, ss, "x1", 0.05)
@@ -134,7 +135,7 @@ def test_default_schedule_sends_full_rounds_to_the_wide_sweeps(hank):
     hb.set_boundary(ss.value, ss.D)
     info = hb.info()
     assert info["wide_supported"] == 1 and info["wide_mode"] == 1
-    for N, fam in ((256, "on-chip-wide"), (32, "xcd-persistent"), (120, "launch-per-period"), (300, "launch-per-period"), (512, "on-chip-wide")):
+    for N, fam in ((256, "on-chip-wide"), (32, "xcd-persistent"), (72, "launch-per-period"), (120, "on-chip-wide"), (300, "on-chip-wide"), (512, "on-chip-wide")):
         y = np.random.default_rng(N).standard_normal((2, P, N))
         agg, dagg = hb.primal_jvp(x[2:4], y)
         assert hb.info()["last_tangent_family_name"] == fam, (N, hb.info())
