@@ -259,7 +259,7 @@ static int build_primal_graphs(hank_ctx *ctx) {
                        ctx->R.s + (size_t)(P - 1) * c.G, ctx->R.kc + (size_t)(P - 1) * c.G, ctx->d_err, P - 1, (const int *)nullptr);
     for (int t = P - 1; t >= 0; t--)
         hipLaunchKernelGGL(k_egm_step, grd, blk, lds, s, c, ctx->R, ctx->d_xhh, t, ctx->d_err);
-    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, P * c.n_e, ctx->d_err, 1);
+    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, P * c.n_e, ctx->d_err, 1, 1);
     int rc = end_capture(ctx, &ctx->g_pback);
     if (rc) return rc;
     // forward
@@ -370,7 +370,7 @@ static int capture_tangent_graphs(hank_ctx *ctx, TanWork &w, int which) {
             cur ^= 1;
         }
     }
-    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err, 1);
+    hipLaunchKernelGGL(k_lottery, dim3(P * c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err, 1, 1);
     rc = end_capture(ctx, &w.g_fback);
     if (rc) return rc;
     HIPC(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -746,7 +746,7 @@ static int x_run_primal(hank_ctx *ctx, bool skip_fwd = false, XTan *dual = nullp
     else hipLaunchKernelGGL((k_xprimal_back<1024>), grd, blk, ldsb, s, ab);
     HIPC(ctx, hipEventRecord(ctx->ev[1], s));
     // (the Dual pass's forward half reads the lottery through its work units: the per-target segment records are built when somebody asks)
-    hipLaunchKernelGGL(k_lottery, dim3((unsigned)(P * c.n_e)), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err, dual ? 0 : 1);
+    hipLaunchKernelGGL(k_lottery, dim3((unsigned)(P * c.n_e)), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, ctx->R, (int)P * c.n_e, ctx->d_err, dual ? 0 : 1, 1);
     ctx->seg_valid = !dual;
     X.rng_valid = false;
     x_ensure_rng(ctx);
@@ -2206,7 +2206,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
     HIPC(ctx, hipMemcpyAsync(Dchk, D_io, sizeof(double) * G, hipMemcpyHostToDevice, s));
     HIPC(ctx, hipMemsetAsync(state, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, s, ctx->d_err, 4);
-    hipLaunchKernelGGL(k_lottery, dim3((unsigned)c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, R, c.n_e, ctx->d_err, 1);
+    hipLaunchKernelGGL(k_lottery, dim3((unsigned)c.n_e), dim3(256), sizeof(int) * (2 * (size_t)c.n_a + 2), s, c, R, c.n_e, ctx->d_err, 1, 0);
     HIPC(ctx, hipGetLastError());
     const dim3 blk(RBP * c.n_e), grd(ctx->nbp);
     int hstate[2] = {0, 0}, done = 0;

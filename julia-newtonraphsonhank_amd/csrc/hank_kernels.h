@@ -392,7 +392,7 @@ __global__ void k_egm_step(Consts c, Record R, const double *xhh, int t, int *er
 //              tangent — the borrowing-constraint mass point, summed separately (it is long);
 //   start[r] = max(clo, first source j with lo_j >= r): target row r receives w_j from the sources
 //              in [start[r-1], start[r]) and 1-w_j from those in [start[r], start[r+1]).
-__global__ void k_lottery(Consts c, Record R, int ncols, int *err, int write_seg) {
+__global__ void k_lottery(Consts c, Record R, int ncols, int *err, int write_seg, int use_ib) {
     extern __shared__ int shlo[];
     __shared__ int sh_clo;
     const int col = blockIdx.x;
@@ -405,6 +405,15 @@ __global__ void k_lottery(Consts c, Record R, int ncols, int *err, int write_seg
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         const double p = R.pol[base + j];
         int lo = -1, hi = n;  // grid[lo] < p <= grid[hi]  (searchsortedfirst, :52)
+        if (use_ib) {
+            // the policy is the interpolation's convex combination of grid[ib] and grid[ib + 1] (egm_Y): its lottery bracket is the
+            // interpolation's unless it sits on a grid point or was moved by the borrowing constraint — a probe of that bracket and
+            // of the one below replaces the 11 dependent loads of the bisection (which still decides whatever the probe does not)
+            const int g0 = min(max(R.ib[base + j], 0), n - 2);
+            const double a0 = c.a[g0], a1 = c.a[g0 + 1];
+            if (a0 < p && p <= a1) { lo = g0; hi = g0 + 1; }
+            else if (g0 > 0 && p <= a0 && c.a[g0 - 1] < p) { lo = g0 - 1; hi = g0; }
+        }
         while (hi - lo > 1) {
             const int mid = lo + ((hi - lo) >> 1);
             if (c.a[mid] < p) lo = mid; else hi = mid;
