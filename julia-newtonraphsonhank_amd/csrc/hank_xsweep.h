@@ -1242,7 +1242,15 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     double polr = 0.0, Dr = 0.0, lwr = 0.0, igr = 0.0, dpr[DD];
 #pragma unroll
     for (int k = 0; k < DD; k++) dpr[k] = 0.0;
-    auto prefetch = [&](int t) {
+    // dev timing build (wrong numbers): HANK_X_TIMING_L2 confines what a period READS of the record and of the policy partials to
+    // two periods — every such load an L2 / Infinity-Cache hit: what the HBM latency of the sweep's input streams costs
+#ifdef HANK_X_TIMING_L2
+#define XTPER(t) ((t) & 1)
+#else
+#define XTPER(t) (t)
+#endif
+    auto prefetch = [&](int t_) {
+        const int t = XTPER(t_);
         const size_t ro = (size_t)t * G + (size_t)e * na + (own ? r : 0);       // (a virtual row carries row 0's policy and partials)
         polr = R.pol[ro];
         if constexpr (D > 0) xload_row_plain<DD>(A.dpol + ((size_t)t * A.groups + x) * (size_t)G * D + ((size_t)e * na + (own ? r : 0)) * D, dpr);
@@ -1262,8 +1270,9 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
     };
     // (branch-free: every lane loads — a lane beyond the unit's sources the unit's last row, an empty unit row 0 of column 0 — and
     // qon / qvl say what counts)
-    auto load_rec = [&](auto U, int t, int2 d, int i0) {
+    auto load_rec = [&](auto U, int t_, int2 d, int i0) {
         constexpr int u = decltype(U)::value;
+        const int t = XTPER(t_);
         const int ue = d.x & 15, ja = (d.x >> 4) & 0xfff, cnt = (d.x >> 16) & 0xfff, nv = (d.y >> 16) & 0xff;
         const int i = i0 + lane;
         const bool real = i < cnt;
