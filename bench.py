@@ -204,13 +204,31 @@ def extra_measurements(hb, d_x, P, N, dev, torch_stream=None):
     b_alg_w = 2 * P * G8 * (1 + Nw)
     slow = kb if tm[kb]["ms"] >= tm[kf]["ms"] else kf
     ach_w = G8 * per / (1e-3 * tm[slow]["ms"]) / 1e9
+    # fabric traffic of that kernel from the counter passes of scripts/dev_pmc_wide.sh (same hash rule as the headline's)
+    traffic_w, stale_w, pmc_w = None, None, None
+    try:
+        rec = json.loads((ROOT / "profiles" / "pmc_latest.json").read_text()).get("ks_2000x11_T300_N256", {})
+        pmc_w = rec.get(kpre + ("back" if slow == kb else "fwd"))
+        if pmc_w:
+            traffic_w, stale_w = pmc_w["hbm_bytes"], rec.get("kernel_source_sha16") != kernel_source_sha16()
+    except (OSError, ValueError, KeyError):
+        pass
+    # the y-iteration's pattern at this width: JVP batches at the recorded primal
+    hb.jvp_dev(d_dx.data_ptr(), Nw, d_out.data_ptr()); hb.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        hb.jvp_dev(d_dx.data_ptr(), Nw, d_out.data_ptr())
+    hb.sync()
+    el_j = (time.perf_counter() - t0) / reps
     extra["wide_batch"] = {"tangents": Nw, "JVPs_per_s": Nw / el, "ms_per_step": 1e3 * el, "passes": np_, "family": fam,
+                           "jvp_at_recorded_primal": {"JVPs_per_s": Nw / el_j, "ms_per_batch": 1e3 * el_j},
                            "sweeps_ms": {k: round(v["ms"], 4) for k, v in tm.items() if v["ms"] > 0},
                            "backward_sweep_GBs": G8 * per / (1e-3 * tm[kb]["ms"]) / 1e9,
                            "forward_sweep_GBs": G8 * per / (1e-3 * tm[kf]["ms"]) / 1e9,
                            # the same object as the headline's, for the slower sweep of the wide batch (HIP events on the library's stream)
                            "roofline": {"bound": "hbm", "kernel": kpre + ("back" if slow == kb else "fwd"),
-                                        "achieved": ach_w, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_w / HBM_PEAK_GBS, "traffic": None,
+                                        "achieved": ach_w, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_w / HBM_PEAK_GBS, "traffic": traffic_w,
+                                        "traffic_stale": stale_w, "traffic_detail": pmc_w, "bytes_per_launch": G8 * per,
                                         "sweep_ms": tm[slow]["ms"], "launches": tm[slow]["launches"], "model_ceiling": model_ceiling(hb.G, Nw, hb.n_e)},
                            "whole_batch": {"B_alg_bytes": b_alg_w, "achieved_GBs": b_alg_w / el / 1e9, "frac_of_hbm_peak": b_alg_w / el / 1e9 / HBM_PEAK_GBS}}
     # the y-iteration's access pattern (NewtonRaphson.jl:91-111): ONE primal, then JVP batches at that record

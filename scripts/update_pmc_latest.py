@@ -7,6 +7,34 @@ root = Path(__file__).resolve().parent.parent / "profiles"
 p = root / "pmc_latest.json"
 d = json.loads(p.read_text()) if p.exists() else {}
 
+if (root / f"{tag}_pmc_P1.txt").exists():       # a wide-batch pass (scripts/dev_pmc_wide.sh <tag>): P1 = FETCH_SIZE, P2 = WRITE_SIZE, P3 / P4 = SQ counters
+    def wmean(which, counter, kernel):
+        t = (root / f"{tag}_pmc_{which}.txt").read_text()
+        m = re.search(r"^" + re.escape(kernel) + r"<[^\n]*\n(?:\s+\S+\s+mean\s+[\d.]+\n)*?\s+" + counter + r"\s+mean\s+([\d.]+)", t, re.M)
+        return float(m.group(1)) if m else None
+    wl = d.setdefault("ks_2000x11_T300_N256", {})
+    for k in ("k_wide_back", "k_wide_fwd", "k_fused_back", "k_fused_fwd"):
+        f, w = wmean("P1", "FETCH_SIZE", k), wmean("P2", "WRITE_SIZE", k)
+        if f is None or w is None:
+            continue
+        waves, valu, wcyc, wany, avalu = (wmean("P3", n, k) for n in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"))
+        c = {}
+        if waves and valu:
+            c["valu_insts_per_wave"] = valu / waves
+        if wcyc and wany is not None:
+            c["parked_frac"] = wany / wcyc
+        if wcyc and avalu is not None:
+            c["active_valu_frac"] = avalu / wcyc
+        wl[k] = {"fetch_bytes": 2.0 * f * 1024, "write_bytes": w * 1024, "hbm_bytes": 2.0 * f * 1024 + w * 1024, "profile_tag": tag, "counters": c,
+                 "note": f"rocprofv3 --pmc (separate passes, profiles/{tag}_pmc_P1..P4.txt, scripts/dev_pmc_wide.sh), per launch; FETCH_SIZE x2, see the N32 entry"}
+    sys.path.insert(0, str(root.parent))
+    from bench import kernel_source_sha16  # noqa: E402
+    wl["kernel_source_sha16"] = kernel_source_sha16()
+    wl["profile_tag"] = tag
+    p.write_text(json.dumps(d, indent=1))
+    print(json.dumps({k: v["hbm_bytes"] for k, v in wl.items() if isinstance(v, dict)}))
+    sys.exit(0)
+
 
 def mean_kb(counter, kernel):
     t = (root / f"{tag}_pmc_{counter}_summary.txt").read_text()
