@@ -33,6 +33,9 @@
 // What was measured on the way (a dual kernel carrying value and partials together, a run-ahead wave, atomic-counter
 // barriers, ...) is in DESIGN.md section 4.
 #pragma once
+#ifndef HANK_XFWD_PRECOMBINE
+#define HANK_XFWD_PRECOMBINE 1     // k_xfwd: neighbouring lanes' parts for one tile row in one LDS add (dev knob: 0 = one add per part)
+#endif
 #include "hank_kernels.h"
 #include <type_traits>
 
@@ -1405,7 +1408,46 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
 #ifdef HANK_DEV_NOATOMIC      // timing experiment only (wrong numbers): what the same-address serialisation of the LDS adds costs
 #define lds_add(p, v) (*(p) = (v))
 #endif
-            auto process = [&](auto U, int2 d) {
+            // PRE-COMBINE (round 5). The sources of a unit are consecutive lanes and their brackets rise with them: where the policy moves
+            // one grid row per source row — most of the grid — the upper part of lane i-1 and the lower part of lane i land on the SAME
+            // tile row. Lane i then adds both in one ds_add_f64 (the neighbour's part arrives by a wave_shr:1 DPP move) and lane i-1
+            // skips its own: half the LDS atomics of the walk (20 per wave and period at D = 4 with the value; a timing build without
+            // them put their cost at 0.33 ms of the sweep). Still one unit = one wave in program order: reproducible bit for bit; where a
+            // row receives exactly these two terms the sum is the same (0 + L) + H = 0 + (L + H).
+            auto process_pc = [&](auto U, int2 d) {
+                constexpr int u = decltype(U)::value;
+                const int ta = d.y & 0xff, tb = (d.y >> 8) & 0xff;
+                double *const colt = tile + (size_t)(d.x & 15) * 64 * SL;
+                const double w = qw[u], w1 = 1.0 - w;
+                double gD = qg[u], Dv = 0.0;
+                if constexpr (VAL) { Dv = dd[u][IV]; gD = qg[u] * Dv; }
+                else { if (qvl[u]) gD = 0.0; }          // (a virtual row's mass is part of the recorded ig * D of row 0)
+                const int tl = qlo[u] - r0, th = tl + 1;
+                const bool doL = qon[u] && tl >= ta && tl < tb, doH = qon[u] && th >= ta && th < tb;
+                const int thp = __builtin_amdgcn_update_dpp(-2, doH ? th : -2, 0x138, 0xf, 0xf, false);        // lane i-1's upper target (wave_shr:1; lane 0: none)
+                const bool take = doL && thp == tl;
+                const bool given = __builtin_amdgcn_update_dpp(0, take ? 1 : 0, 0x130, 0xf, 0xf, false) != 0;   // lane i+1 adds my upper part with its lower one (wave_shl:1)
+                double *const tpl = colt + (size_t)(doL ? tl : 0) * SL, *const tph = colt + (size_t)(doH ? th : 0) * SL;
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    const double hk = w * dd[u][k] + gD * qdp[u][k];
+                    const double hp = xdpp<0x138, 0xf, 0xf>(hk);
+                    const double lk = w1 * dd[u][k] - gD * qdp[u][k];
+                    if (doL) lds_add(tpl + k, take ? lk + hp : lk);
+                    if (doH && !given) lds_add(tph + k, hk);
+                }
+                if constexpr (VAL) {                    // (the VALUE keeps one add per part: D_t — the record — is the same bits whichever kernel carries it)
+                    if (doL) lds_add(tpl + IV, w1 * Dv);
+                    if (doH) lds_add(tph + IV, w * Dv);
+                }
+                if constexpr (!VAL) {
+                    if (doL && !qvl[u]) {               // (every unclamped source has exactly one lower target: its aggregate term is taken here, once)
+#pragma unroll
+                        for (int k = 0; k < D; k++) pagg[k] += qdp[u][k] * qdn[u];
+                    }
+                }
+            };
+            auto process_1 = [&](auto U, int2 d) {
                 constexpr int u = decltype(U)::value;
                 if (!qon[u]) return;
                 const int ta = d.y & 0xff, tb = (d.y >> 8) & 0xff;
@@ -1434,6 +1476,10 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
                     if constexpr (VAL) lds_add(tp + IV, w * Dv);
                 }
             };
+            // (narrow kernels — one or two slots per tile row — keep one add per part: at D = 1 the exchange costs more than the
+            // one atomic it saves, single-tangent JVP 1.98 -> 2.06 ms)
+            constexpr bool PRECOMB = HANK_XFWD_PRECOMBINE && (D + (VAL ? 1 : 0)) >= 3;
+            auto process = [&](auto U, int2 d) { if constexpr (PRECOMB) process_pc(U, d); else process_1(U, d); };
             process(I0, ud[0]);
             process(I1, ud[1]);
 #ifdef HANK_DEV_NOATOMIC

@@ -130,7 +130,9 @@ def test_persistent_sweeps_are_race_free_at_full_size(hank):
     y = np.random.default_rng(21).standard_normal((2, P, 32))
     first = hb.jvp(y)
     one = hb.jvp(y[:, :, 7:8])
-    assert np.array_equal(one[:, 0], first[:, 7])          # a direction's result does not depend on its batch
+    # a direction's result does not depend on its batch — to rounding: the forward sweep of a batch with four partials per group adds
+    # neighbouring sources' parts for one tile row in ONE LDS add (pre-combine, round 5), the single-direction kernel keeps one add per part
+    assert np.max(np.abs(one[:, 0] - first[:, 7])) <= 1e-13 * np.max(np.abs(first[:, 7]))
     for _ in range(25):
         assert np.array_equal(hb.jvp(y), first)
         assert np.array_equal(hb.jvp(y[:, :, 7:8]), one)
