@@ -1390,9 +1390,7 @@ __global__ void __launch_bounds__(MAXT) k_xfwd(XSweepFwdArgs A) {
         if (sync_duty) xpoll(A.sy, x, sw & 255, (sw >> 8) & 255, (unsigned)(t + 1));   // this period's source members have published period t-1
         xlds_barrier();
         XSTAMP(1, son, t, 1);
-#ifndef HANK_DEV_NOAGG      // timing experiment only (wrong aggregates): what the sync wave's reduction costs the period
         if (sync_duty && t > 0) reduce_agg(t - 1);      // (the sync wave has nothing else to do until the gathers are done)
-#endif
         double pagg[DD];
 #pragma unroll
         for (int k = 0; k < DD; k++) pagg[k] = 0.0;
