@@ -866,6 +866,23 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
     int ibY = 0;
     double cA = 0.0, cB = 0.0, cu = 0.0, cv = 0.0, ck = 0.0, cs = 0.0;
     if (own) { cs = R.s[(size_t)(P - 1) * G + pt]; if (!c.diet) ck = R.kc[(size_t)(P - 1) * G + pt]; }
+    // ... and, since round 5, TWO trips ahead: these are cold lines of the record (2-3 us from HBM under this load) and a trip is
+    // ~4 us, but the loads used to be issued behind the publish and needed right behind the next poll — a flag round (~1 us) later.
+    // A second register set (n_*) is loaded a whole trip before it is needed and handed over at the end of the trip.
+    int n_ib = 0;
+    double n_A = 0.0, n_B = 0.0, n_u = 0.0, n_v = 0.0, n_k = 0.0, n_s = 0.0;
+    auto load_next = [&](int ty) {                      // the record of Y(ty) and X(ty - 1); ty < 0: nothing left to load
+        if (own && ty >= 0) {
+            const size_t ro = (size_t)ty * G + pt;
+            n_ib = R.ib[ro]; n_A = R.A[ro]; n_B = R.B[ro]; n_u = R.u[ro];
+            if (!c.diet) n_v = R.v[ro];
+            if (ty > 0) { n_s = R.s[ro - G]; if (!c.diet) n_k = R.kc[ro - G]; }
+        }
+    };
+    // (narrow kernels only: single tangent 1.96 -> 1.90 ms, N = 16 2.40 -> 2.35; at D = 4 the second set costs 26 registers and the
+    // trip — longer there — already covers most of the latency: 3.24 -> 3.28 ms, so D = 4 keeps the one-trip form)
+    constexpr bool DEEP = D <= 2;
+    if constexpr (DEEP) load_next(P - 1);               // what trip 1 uses
     // sequence: X(P-1) | Y(P-1) X(P-2) | ... | Y(1) X(0) | Y(0); member c publishes episode i+1 when the stores of trip i have drained
     const int son = (x == 0 && cW < 32) ? cW : -1;     // dev stamps (make stamp)
     (void)son;
@@ -924,7 +941,13 @@ __global__ void __launch_bounds__(MAXT) k_xtan_back(XTanBackArgs A) {
             xbar_arrive(!syncw);                                         // this member's stores have reached L2
             XSTAMP(0, son, i, 5);
             if (sync_duty && !(A.stall && x == 0 && cW == 0 && i > 2)) xpublish(A.sy, x, cW, (unsigned)(i + 1));
-            if (own) {      // the record the next trip needs (Y of period tx, X of period tx - 1): in flight while the others arrive
+            // the record the next trip needs (Y of period tx, X of period tx - 1) was requested a trip ago: hand it over, and request
+            // the one after (in flight through the whole next trip)
+            if constexpr (DEEP) {
+                ibY = n_ib; cA = n_A; cB = n_B; cu = n_u; cv = n_v;
+                if (tx > 0) { cs = n_s; ck = n_k; }
+                load_next(tx - 1);
+            } else if (own) {      // in flight while the others arrive
                 const size_t ro = (size_t)tx * G + pt;
                 ibY = R.ib[ro]; cA = R.A[ro]; cB = R.B[ro]; cu = R.u[ro];
                 if (!c.diet) cv = R.v[ro];
