@@ -136,8 +136,9 @@ int hank_check(hank_ctx *ctx);
  * recomputes the primal (NewtonRaphson.jl:95; GeneralStructures.jl:546-547), so value and N partials
  * travel together. One call = hank_primal + hank_jvp, but both recurrences advance together: a batch of one pass
  * (N <= 32) as TWO persistent launches that carry value and partials in every workgroup group (k_xdual_back, k_xfwd<D, true>),
- * a wider batch as ONE chain of T launches per direction (the tangent sweep runs one period behind the primal sweep inside
- * the same launches). Leaves the context exactly as hank_primal followed by hank_jvp would.
+ * a batch of 33 to 79 directions as ONE chain of T launches per direction (the tangent sweep runs one period behind the primal
+ * sweep inside the same launches), a batch of at least HANK_WIDE_MIN = 80 directions as the Float64 sweeps followed by the on-chip
+ * wide sweeps (one workgroup per direction: hank_wide.h). Leaves the context exactly as hank_primal followed by hank_jvp would.
  * PRIMAL MEMO (host-pointer form only): y_Iteration calls JVP(fullFunction, x, y) about 21 times per Newton step at ONE x
  * (NewtonRaphson.jl:91-95). When `xhh` and the boundary are bit-identical to the ones whose linearisation is on record,
  * hank_primal_jvp runs the tangent sweeps alone (= hank_jvp) and returns the recorded value: results equal the un-memoised
