@@ -263,3 +263,35 @@ def test_segment_records_are_built_on_demand_behind_a_persistent_dual_pass(hank)
     assert hb.info()["last_tangent_family_name"] == "launch-per-period"
     close(got, want, rel=1e-11)                                                 # (stale records — the other x's segments — are off by percents)
     assert hb.stats()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("n_a,n_e,T,N", [(130, 3, 40, 6), (500, 4, 300, 32), (200, 7, 40, 17)])
+def test_device_pointer_dual_pass_equals_the_host_pointer_one(hank, n_a, n_e, T, N):
+    """hank_primal_jvp_dev of a one-pass batch wraps its two sweeps in ONE launch in front and ONE behind (k_xdual_prologue /
+    k_xdual_epilogue: inputs read where they lie, sync blocks zeroed, aggregates summed in k_reduce_parts' order and written to the
+    caller's buffers); the host-pointer form keeps the separate copies and launches. Same bits: the value, the partials, both
+    aggregates of the second heterogeneous output, and the record a later hank_jvp reads."""
+    import torch
+    m, ss, _ = ks_setup(n_a, n_e, T)
+    P = T - 1
+    x, _ = ks_paths(m, ss, "x1", 0.05)
+    y = np.random.default_rng(N).standard_normal((2, P, N))
+    hb = hank.household_block(m)
+    hb.set_boundary(ss.value, ss.D)
+    agg, dagg = hb.primal_jvp(x[2:4], y)
+    assert hb.info()["last_tangent_family_name"] == "xcd-persistent" and hb.last_timings()["tangent_forward"]["launches"] == 1
+    het = hb.het_outputs(2, y)
+    again = hb.jvp(y)
+    dev = torch.device("cuda", 0)
+    d_x = torch.from_numpy(np.asfortranarray(x[2:4]).reshape(-1, order="F").copy()).to(dev)
+    d_y = torch.from_numpy(np.asfortranarray(y).reshape(-1, order="F").copy()).to(dev)
+    d_a = torch.full((P,), np.nan, dtype=torch.float64, device=dev); d_d = torch.full((P * N,), np.nan, dtype=torch.float64, device=dev)
+    hb.primal(x[2:4] * 1.01)                                                     # (another record in between)
+    hb.primal_jvp_dev(d_x.data_ptr(), d_y.data_ptr(), N, d_a.data_ptr(), d_d.data_ptr())
+    hb.sync(); hb.check()
+    assert np.array_equal(d_a.cpu().numpy(), agg)
+    assert np.array_equal(d_d.cpu().numpy().reshape(P, N, order="F"), dagg)
+    het2 = hb.het_outputs(2, y)
+    assert np.array_equal(het2[0], het[0]) and np.array_equal(het2[1], het[1])
+    assert np.array_equal(hb.jvp(y), again)
+    assert hb.stats()["fallbacks"] == 0
