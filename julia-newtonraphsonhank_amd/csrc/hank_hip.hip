@@ -472,13 +472,13 @@ static int fetch_device_error(hank_ctx *ctx) {
         // the kernels behind it then found in it (a "non-monotone policy", say) is not an error of the model — report the sweep
         const int xs = x_status(ctx);
         if (xs) {
-            if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
+            if (e[0] != 0) HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(e), ctx->stream));
             return xs;
         }
     }
     if (e[0] == 0) return HANK_OK;
     ctx->primal_done = false;
-    HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));      // reported once: the next call starts clean
+    HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(e), ctx->stream));      // reported once: the next call starts clean
     switch (e[0]) {
     case ERR_KNOTS:
         return fail(ctx, HANK_ERR_KNOTS,
@@ -558,7 +558,7 @@ static int x_setup(hank_ctx *ctx) {
     X.dmax = X.maxt == 768 ? XD_MAX : 2;
     const size_t G = c.G, GV = G + 64 * (size_t)c.n_e, P = c.P;
     HIPC(ctx, dmalloc(&X.sync, (size_t)2 + 2 * XPASS_MAX));
-    HIPC(ctx, hipMemset(X.sync, 0, sizeof(XSync) * ((size_t)2 + 2 * XPASS_MAX)));      // x_status reads blocks 0, 1 also when the launches recorded the primal
+    HIPC(ctx, hipMemsetAsync(X.sync, 0, sizeof(XSync) * ((size_t)2 + 2 * XPASS_MAX), ctx->stream));      // x_status reads blocks 0, 1 also when the launches recorded the primal
     HIPC(ctx, dmalloc(&X.st_s, 2 * XG * G));
     HIPC(ctx, dmalloc(&X.st_ds, 2 * XG * G * X.dmax));
     const size_t GM = (size_t)c.n_e * X.Sact * 64;       // member-major state of the forward sweeps: [n_e][members][64]
@@ -571,7 +571,7 @@ static int x_setup(hank_ctx *ctx) {
     HIPC(ctx, dmalloc(&X.srcF, P * X.Sact));
     HIPC(ctx, dmalloc(&X.unitsF, P * X.Sact * XUCAP));
     HIPC(ctx, dmalloc(&X.unit_overflow, 1));
-    HIPC(ctx, hipMemset(X.unit_overflow, 0, sizeof(int)));
+    HIPC(ctx, hipMemsetAsync(X.unit_overflow, 0, sizeof(int), ctx->stream));
     if (const char *ng = getenv("HANK_XNEIGH")) X.neigh = atoi(ng) != 0;
     if (const char *uc = getenv("HANK_XUCAP")) X.ucap = std::min(XUCAP, std::max(1, atoi(uc)));
     {   // the bound on every wait inside a persistent sweep, in 100 MHz ticks (read once, here)
@@ -587,7 +587,7 @@ static int x_setup(hank_ctx *ctx) {
         const char *w = strchr(xf, ':');
         X.fault_where = !w ? 7 : (strcmp(w, ":primal") == 0 ? 1 : (strcmp(w, ":tangent") == 0 ? 2 : (strcmp(w, ":fixedpoint") == 0 ? 4 : 7)));
     }
-    HIPC(ctx, hipMemset(X.Dvirt, 0, sizeof(double) * P * c.n_e * 64));
+    HIPC(ctx, hipMemsetAsync(X.Dvirt, 0, sizeof(double) * P * c.n_e * 64, ctx->stream));
     X.ready = true;
     return HANK_OK;
 }
@@ -635,7 +635,7 @@ static int x_ensure_tan(hank_ctx *ctx, int N, XTan **out) {
         HIPC(ctx, dmalloc(&w.dpol, off));
         const size_t W = (size_t)XG * X.dmax, nb = (size_t)X.Sact;
         HIPC(ctx, dmalloc(&w.daggpart, 2 * P * nb * W));              // both aggregates: [P][members][2 W]
-        HIPC(ctx, hipMemset(w.daggpart, 0, sizeof(double) * 2 * P * nb * W));
+        HIPC(ctx, hipMemsetAsync(w.daggpart, 0, sizeof(double) * 2 * P * nb * W, ctx->stream));
         HIPC(ctx, dmalloc(&w.dagg_pass, 2 * P * W));
         HIPC(ctx, dmalloc(&w.dagg_cm, 2 * P * N));                    // (P, 2 N) column-major
         return HANK_OK;
@@ -873,7 +873,7 @@ static int x_status(hank_ctx *ctx) {
     int uo = 0;
     HIPC(ctx, hipMemcpy(&uo, X.unit_overflow, sizeof(int), hipMemcpyDeviceToHost));
     if (uo) {
-        HIPC(ctx, hipMemset(X.unit_overflow, 0, sizeof(int)));
+        HIPC(ctx, hipMemsetAsync(X.unit_overflow, 0, sizeof(int), ctx->stream));
         ctx->primal_done = false;
         X.rng_valid = false;
         for (XTan &t : X.tans) t.valid = false;
@@ -1147,7 +1147,7 @@ int hank_create_on(const hank_model *m, int32_t device, hank_ctx **out) {
     HIPC(ctx, dmalloc(&ctx->d_zd, 2 * P));
     HIPC(ctx, dmalloc(&ctx->d_aggpart, 2 * P * (size_t)ctx->nbp));
     HIPC(ctx, dmalloc(&ctx->d_err, 4));
-    HIPC(ctx, hipMemset(ctx->d_err, 0, 4 * sizeof(int)));
+    HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, 4 * sizeof(int), ctx->stream));
     HIPC(ctx, hipEventCreateWithFlags(&ctx->ev_stream, hipEventDisableTiming));
     // schedule (measured on MI355X): "auto" wherever the grid fits one 63-row slab per CU of an XCD —
     // the Float64 sweeps alone (hank_primal) and narrow tangent batches at a recorded primal (hank_jvp, N <= 64) run as
@@ -2117,7 +2117,7 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
         if (hsy.status[0] == 0) {
             int e[4];
             HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
-            if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
+            if (e[0] != 0) HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(e), ctx->stream));
             if (e[0] == ERR_KNOTS)
                 return fail(ctx, HANK_ERR_KNOTS, "knot-vectors must be unique and sorted in increasing order (steady-state value iteration, step %d, "
                             "productivity state %d, wealth index %d)", xs[0], e[2] + 1, e[3] + 1);
@@ -2158,7 +2158,7 @@ extern "C" int hank_vfi(hank_ctx *ctx, const double *xhh_t, double tol, int32_t 
         HIPC(ctx, hipStreamSynchronize(s));
         int e[4];
         HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
-        if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
+        if (e[0] != 0) HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(e), ctx->stream));
         if (e[0] == ERR_KNOTS)
             return fail(ctx, HANK_ERR_KNOTS, "knot-vectors must be unique and sorted in increasing order (steady-state value iteration, step %d, "
                         "productivity state %d, wealth index %d)", hstate[1] + 1, e[2] + 1, e[3] + 1);
@@ -2239,7 +2239,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
         if (hsy.status[0] == 0) {
             int e[4];
             HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
-            if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
+            if (e[0] != 0) HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(e), ctx->stream));
             if (e[0] == ERR_NONMONO) return fail(ctx, HANK_ERR_NONMONOTONE, "savings policy is not monotone in wealth (productivity state %d, wealth index %d)", e[2] + 1, e[3] + 1);
             HIPC(ctx, hipMemcpyAsync(D_io, D[1], sizeof(double) * G, hipMemcpyDeviceToHost, s));
             HIPC(ctx, hipStreamSynchronize(s));
@@ -2268,7 +2268,7 @@ extern "C" int hank_stationary_dist(hank_ctx *ctx, const double *policy, double 
     }
     int e[4];
     HIPC(ctx, hipMemcpy(e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e[0] != 0) HIPC(ctx, hipMemset(ctx->d_err, 0, sizeof(e)));
+    if (e[0] != 0) HIPC(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(e), ctx->stream));
     if (e[0] == ERR_NONMONO) return fail(ctx, HANK_ERR_NONMONOTONE, "savings policy is not monotone in wealth (productivity state %d, wealth index %d)", e[2] + 1, e[3] + 1);
     // once converged the iteration kernels stop touching the buffers: Dchk holds the last checked iterate
     HIPC(ctx, hipMemcpyAsync(D_io, Dchk, sizeof(double) * G, hipMemcpyDeviceToHost, s));
