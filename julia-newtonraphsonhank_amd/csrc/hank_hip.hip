@@ -201,14 +201,16 @@ static int hip_status(hipError_t e) {
 // a context belongs to ONE HIP device (hank_create: the current one; hank_create_on: the one named). Every entry point
 // makes that device current for the duration of the call and restores the caller's, so one host thread can drive one
 // context per GPU of a node (GeneralStructures.jl:542-550 has no notion of a device: the shim owns the placement).
+static void x_section_release(int dev);
 struct DeviceGuard {
-    int prev = -1;
+    int prev = -1, dev = -1;
     bool switched = false, ok = true;
     explicit DeviceGuard(const hank_ctx *ctx);
-    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    ~DeviceGuard() { if (dev >= 0) x_section_release(dev); if (switched) (void)hipSetDevice(prev); }
 };
 DeviceGuard::DeviceGuard(const hank_ctx *ctx) {
     if (!ctx) return;
+    dev = ctx->device & 63;
     if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
     if (prev != ctx->device) { switched = hipSetDevice(ctx->device) == hipSuccess; ok = switched; }
 }
@@ -503,6 +505,16 @@ static int fetch_device_error(hank_ctx *ctx) {
 // the previous one through one event per device.
 static std::mutex g_xmutex;
 static hipEvent_t g_xlast[64] = {};
+// ... and the launches of ONE call are enqueued as one block: between x_serialize_begin and x_serialize_end this thread holds the
+// device's section lock, so a second host thread (another context on the same GPU: parallel.DeviceGroup) cannot wait for the event
+// of the call BEFORE and then enqueue its sweeps beside this call's. Nested sections of one thread count (the one-pass Dual pass
+// opens one around its prologue, its two halves open their own inside); a section left open by an early return is closed when the
+// entry point returns (DeviceGuard).
+static std::mutex g_xsection[64];
+static thread_local int t_xdepth[64];
+static void x_section_release(int dev) {
+    if (t_xdepth[dev] > 0) { t_xdepth[dev] = 0; g_xsection[dev].unlock(); }
+}
 
 // dynamic LDS of the persistent kernels (the expressions the kernels carve up): it grows with the horizon P
 static size_t x_lds_primal_back(const Consts &c) { return sizeof(double) * ((size_t)c.n_e * 64 + (size_t)c.n_e * c.n_e + c.n_a + 4 * (size_t)c.P) + 64; }
@@ -690,15 +702,21 @@ static int ensure_seg(hank_ctx *ctx) {       // before a reader of R.seg (launch
     return HANK_OK;
 }
 static int x_serialize_begin(hank_ctx *ctx) {
+    const int d = ctx->device & 63;
+    if (t_xdepth[d]++ == 0) g_xsection[d].lock();
     std::lock_guard<std::mutex> lk(g_xmutex);
-    if (g_xlast[ctx->device & 63]) HIPC(ctx, hipStreamWaitEvent(ctx->stream, g_xlast[ctx->device & 63], 0));
+    if (g_xlast[d]) HIPC(ctx, hipStreamWaitEvent(ctx->stream, g_xlast[d], 0));
     return HANK_OK;
 }
 static int x_serialize_end(hank_ctx *ctx) {
-    std::lock_guard<std::mutex> lk(g_xmutex);
-    hipEvent_t &e = g_xlast[ctx->device & 63];
-    if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIPC(ctx, hipEventRecord(e, ctx->stream));
+    const int d = ctx->device & 63;
+    {
+        std::lock_guard<std::mutex> lk(g_xmutex);
+        hipEvent_t &e = g_xlast[d];
+        if (!e) HIPC(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPC(ctx, hipEventRecord(e, ctx->stream));
+    }
+    if (t_xdepth[d] > 0 && --t_xdepth[d] == 0) g_xsection[d].unlock();
     return HANK_OK;
 }
 
